@@ -103,7 +103,7 @@ typedef struct rtx_scene_desc {
 } rtx_scene_desc;
 
 /* Limits (checked, RTX_ERR_LIMIT when exceeded). */
-#define RTX_MAX_LEAVES 65536u  /* leaf index is 16 bits of the sampler counter */
+#define RTX_MAX_LEAVES 65535u  /* leaf index is 16 bits of the sampler counter */
 #define RTX_MAX_LIGHTS 65535u  /* sample index is the other 16 bits */
 #define RTX_MAX_MATERIALS 256u
 

@@ -1,0 +1,798 @@
+// rtx_amd.hip - MI355X (gfx950) render hot path behind the C ABI of include/rtx.h.
+//
+// One frame = three kernels on one stream, no host round trip in between:
+//   trace_kernel  one lane per pixel: primary ray, box walk, nearest hit per
+//                 leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
+//   shade_kernel  one wave per hit record, lanes over the light samples: shadow
+//                 rays against the record's leaf + BSDF (raytracing.h:36-50,
+//                 shade.h) -> one colour per record
+//   merge_kernel  one lane per pixel: per-nesting-level dominance fold of the
+//                 record colours, clamp, truncate (raytracing.h:85-93, :126-130)
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (see Makefile).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx.h"
+#include "rtx_device.h"
+
+// ===========================================================================
+// Kernels
+// ===========================================================================
+
+#define TRACE_BLOCK 256
+#define SHADE_BLOCK 256
+#define SHADE_WAVES (SHADE_BLOCK / 64)
+#define MERGE_BLOCK 256
+#define MAX_NEST 24 // deepest box nesting the merge handles (checked at scene creation)
+
+// ---- trace ------------------------------------------------------------------
+// Pixels are dealt to waves as 8 x 8 tiles so that the 64 rays of a wave stay
+// close together in the box hierarchy.
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
+    DFrame fr, const DNode *__restrict__ nodes, uint32_t n_nodes, const DPrim *__restrict__ prims,
+    DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
+    DCounters *__restrict__ ctr) {
+    const uint32_t tiles_x = (fr.width + 15) / 16;
+    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t i = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t r = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (i >= fr.width || r >= fr.rows) return;
+    const uint32_t j = part_row(fr, r);
+    const uint32_t pixel = j * fr.width + i;
+    const uint32_t local = r * fr.width + i;
+
+    f3 o, d;
+    primary_ray(fr, i, j, o, d);
+    const f3 inv = f3_make(1.f / d.x, 1.f / d.y, 1.f / d.z); // intersect.h:72-74
+
+    uint32_t head = RTXD_NONE, prev = RTXD_NONE, ordinal = 0;
+    uint32_t n = 0;
+    while (n < n_nodes) {
+        const DNode nd = nodes[n];
+        const bool inner = nd.info == RTXD_NONE;
+        if (!box_hit(o, inv, nd.lb, nd.rt)) {
+            n = inner ? nd.link : n + 1;
+            continue;
+        }
+        if (inner) {
+            n = n + 1;
+            continue;
+        }
+        // leaf (intersect.h:95-132): every primitive is tested, the smallest
+        // distance wins, the earliest primitive on ties
+        const uint32_t first = nd.link, count = nd.info >> 16, leaf = nd.info & 0xFFFFu;
+        float best_t = 0.f;
+        uint32_t best = RTXD_NONE;
+        for (uint32_t k = 0; k < count; k++) {
+            const DPrim *p = prims + first + k;
+            const f3 a = p->a, b = p->b;
+            float t;
+            bool ok;
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                ok = tri_hit(o, d, a, b, p->c, t);
+            else
+                ok = sph_hit(o, d, a, b.y, t);
+            if (ok && (best == RTXD_NONE || t < best_t)) {
+                best_t = t;
+                best = k;
+            }
+        }
+        if (best != RTXD_NONE) {
+            const DPrim *p = prims + first + best;
+            const f3 pos = f3_add(o, f3_scale(d, best_t)); // intersect.h:20, :58
+            const uint32_t tm = p->type_mat;
+            f3 nrm;
+            if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                nrm = p->n;
+            else
+                nrm = f3_normalize(f3_sub(pos, p->a)); // intersect.h:21
+            const uint32_t idx = atomicAdd(&ctr->n_recs, 1u);
+            atomicAdd(&ctr->leaf_prims, (unsigned long long)count);
+            if (idx < rec_cap) {
+                DRec rc;
+                rc.pixel = pixel;
+                rc.node = n;
+                rc.prim = p->id;
+                rc.t = best_t;
+                rc.px = pos.x;
+                rc.py = pos.y;
+                rc.pz = pos.z;
+                rc.mat = tm >> 8;
+                rc.nx = nrm.x;
+                rc.ny = nrm.y;
+                rc.nz = nrm.z;
+                rc.next = RTXD_NONE;
+                rc.leaf = leaf;
+                rc.first = first;
+                rc.count = count;
+                rc.ordinal = ordinal;
+                recs[idx] = rc;
+                if (prev == RTXD_NONE)
+                    head = idx;
+                else
+                    recs[prev].next = idx; // only this lane ever touches its own chain
+                prev = idx;
+            }
+            ordinal++;
+        }
+        n = n + 1;
+    }
+    first_rec[local] = head;
+}
+
+// ---- shade.h -------------------------------------------------------------------
+// shade.h:7-18
+__device__ __forceinline__ float rdm_beckmann(float NdotH, const DMat &m) {
+    if (NdotH > 0.f) {
+        float cos2 = NdotH * NdotH;
+        float tan2 = (1.f - cos2) / cos2;
+        float cos4 = cos2 * cos2;
+        return expf(-tan2 / m.alpha2) / (m.pi_alpha2 * cos4);
+    }
+    return 0.f;
+}
+
+// shade.h:22-33 with extIOR = 1 (the only call site, shade.h:61); powf(x, 2)
+// is taken as x * x.
+__device__ __forceinline__ float rdm_fresnel(float cosI, const DMat &m) {
+    float sinT2 = m.ratio2 * (1.f - (cosI * cosI));
+    if (sinT2 > 1.f) return 1.f;
+    float cosT = __builtin_sqrtf(1.f - sinT2);
+    float a = cosI - cosT * m.ior, b = cosI + cosT * m.ior;
+    float c = cosT - cosI * m.ior, e = cosT + cosI * m.ior;
+    float Rs = (a * a) / (b * b);
+    float Rp = (c * c) / (e * e);
+    return 0.5f * (Rs + Rp);
+}
+
+// shade.h:35-47
+__device__ __forceinline__ float rdm_g1(float DdotH, float DdotN, float alpha) {
+    float tn = __builtin_sqrtf(1.f - DdotN * DdotN) / DdotN;
+    float b = 1.f / (alpha * tn);
+    float k = DdotH / DdotN;
+    if (k > 0.f) {
+        if (b < 1.6f) return (3.535f * b + 2.181f * b * b) / (1.f + 2.276f * b + 2.577f * b * b);
+        return 1.f;
+    }
+    return 0.f;
+}
+
+// shade.h:80-90 with RDM_bsdf, _s and _d inlined.  RDM_bsdf receives LdotH in
+// the place of LdotN (shade.h:88); the true LdotN is only the final cosine.
+__device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
+    f3 h = f3_normalize(f3_add(v, l));
+    float LdotH = f3_dot(l, h);
+    float VdotH = f3_dot(v, h);
+    float NdotH = f3_dot(n, h);
+    float LdotN = f3_dot(l, n);
+    float VdotN = f3_dot(v, n);
+    float dd = rdm_beckmann(NdotH, m);
+    float ff = rdm_fresnel(LdotH, m);
+    float gg = rdm_g1(LdotH, LdotH, m.roughness) * rdm_g1(VdotH, VdotN, m.roughness);
+    f3 s = f3_div(f3_scale(f3_scale(f3_scale(m.spec, dd), ff), gg), 4.f * LdotH * VdotN);
+    f3 bsdf = f3_add(m.dif_pi, s);
+    return f3_scale(f3_mul(lc, bsdf), LdotN);
+}
+
+// ---- shadow + shade ---------------------------------------------------------------
+// One wave per hit record, taken from a device-side queue; lane l of pass q
+// owns light sample 64 q + l.  All lanes of a wave walk the same leaf, so the
+// primitive data is wave-uniform (scalar loads) and only the ray differs per
+// lane.  The shadow-ray origin of sample k is the hit position after k + 1
+// float additions of normal * acne (raytracing.h:40): that chain is inherently
+// serial, so lanes 0..2 (x, y, z) run it 64 steps at a time into LDS and every
+// lane then picks up its own origin.
+__global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
+    DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
+    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
+    DCounters *__restrict__ ctr) {
+    __shared__ float chain[SHADE_WAVES][64 * 3];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *P = chain[wave];
+    const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
+    const float nl = (float)fr.n_lights;
+
+    for (;;) {
+        uint32_t ridx = 0;
+        if (lane == 0) ridx = atomicAdd(&ctr->queue_head, 1u);
+        ridx = __builtin_amdgcn_readfirstlane(ridx);
+        if (ridx >= n_recs) break; // every wave reaches this once the queue is drained
+
+        const DRec rc = recs[ridx];
+        const uint32_t pixel = rc.pixel, leaf = rc.leaf, first = rc.first, count = rc.count;
+        const DMat mat = mats[rc.mat];
+        const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
+        f3 o, d;
+        primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+        const f3 view = f3_scale(d, -1.f);       // raytracing.h:47
+        const f3 step = f3_scale(nrm, fr.acne);  // raytracing.h:40
+        // lanes 0..2: running origin component and its increment
+        float run = lane == 0 ? rc.px : lane == 1 ? rc.py : rc.pz;
+        const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
+
+        f3 acc = f3_make(0.f, 0.f, 0.f);
+        for (uint32_t base = 0; base < fr.n_lights; base += 64) {
+            if (lane < 3) {
+#pragma unroll
+                for (int s = 0; s < 64; s++) {
+                    run = run + inc;
+                    P[s * 3 + lane] = run;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t k = base + lane;
+            if (k < fr.n_lights) {
+                const f3 p = f3_make(P[lane * 3 + 0], P[lane * 3 + 1], P[lane * 3 + 2]);
+                f3 lpos = fr.light_pos;
+                light_sample(fr.seed, pixel, leaf, k, lpos.x, lpos.y);
+                const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
+                // nearest hit of the shadow ray inside the leaf (raytracing.h:45)
+                float tmin = 0.f;
+                bool any = false;
+                for (uint32_t q = 0; q < count; q++) {
+                    const DPrim *pr = prims + first + q;
+                    float t;
+                    bool ok;
+                    if ((pr->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                        ok = tri_hit(p, sd, pr->a, pr->b, pr->c, t);
+                    else
+                        ok = sph_hit(p, sd, pr->a, pr->b.y, t);
+                    if (ok && (!any || t < tmin)) {
+                        tmin = t;
+                        any = true;
+                    }
+                }
+                // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
+                if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
+                    const f3 c = shade(nrm, view, sd, fr.light_color, mat);
+                    acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // sum over the lanes (fixed butterfly order, so a frame is reproducible)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+        }
+        if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    }
+}
+
+// ---- merge -----------------------------------------------------------------------
+// vec3.h:97-101: a colour is "less" only if all three channels are strictly less.
+__device__ __forceinline__ bool all_less(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax < bx && ay < by && az < bz;
+}
+
+// utils.h:3-10; a NaN (which fails both comparisons) is stored as 0.
+__device__ __forceinline__ uint8_t clamp_color(float v) {
+    if (v > 255.f)
+        v = 255.f;
+    else if (v < 0.f)
+        v = 0.f;
+    if (v != v) return 0;
+    return (uint8_t)v;
+}
+
+// Every trace_ray_boxs call (raytracing.h:74-98) folds the colours of its own
+// list of boxes, starting from black, and returns the result to its caller,
+// which folds it into its own colour.  The fold "replace if strictly greater
+// in all channels" is not associative, so the nesting must be reproduced: lev
+// is the nesting level of the list a leaf sits in, acc[lev] the colour of the
+// call that is open at that level.  A box without a hit folds to black and
+// black never replaces anything, so only the hit records matter.
+__global__ __launch_bounds__(MERGE_BLOCK) void merge_kernel(
+    DFrame fr, const DNode *__restrict__ nodes, const DUp *__restrict__ up,
+    const DRec *__restrict__ recs, const float4 *__restrict__ colors,
+    const uint32_t *__restrict__ first_rec, uint8_t *__restrict__ rgb) {
+    const uint32_t local = blockIdx.x * MERGE_BLOCK + threadIdx.x;
+    if (local >= fr.rows * fr.width) return;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    uint32_t r = first_rec[local];
+    if (r != RTXD_NONE) {
+        float ax[MAX_NEST], ay[MAX_NEST], az[MAX_NEST];
+        ax[0] = ay[0] = az[0] = 0.f;
+        uint32_t lev = 0, prev = RTXD_NONE;
+        while (r != RTXD_NONE) {
+            const uint32_t n = recs[r].node;
+            const uint32_t depth = up[n].depth;
+            if (prev != RTXD_NONE) {
+                // close the calls that end between the previous leaf and this one
+                uint32_t a = up[prev].parent, l = up[prev].depth;
+                while (a != RTXD_NONE && nodes[a].link <= n) {
+                    if (all_less(ax[l - 1], ay[l - 1], az[l - 1], ax[l], ay[l], az[l])) {
+                        ax[l - 1] = ax[l];
+                        ay[l - 1] = ay[l];
+                        az[l - 1] = az[l];
+                    }
+                    l--;
+                    a = up[a].parent;
+                }
+                lev = l;
+            }
+            for (uint32_t l = lev + 1; l <= depth; l++) ax[l] = ay[l] = az[l] = 0.f;
+            const float4 c = colors[r];
+            if (all_less(ax[depth], ay[depth], az[depth], c.x, c.y, c.z)) {
+                ax[depth] = c.x;
+                ay[depth] = c.y;
+                az[depth] = c.z;
+            }
+            lev = depth;
+            prev = n;
+            r = recs[r].next;
+        }
+        for (uint32_t l = lev; l >= 1; l--) {
+            if (all_less(ax[l - 1], ay[l - 1], az[l - 1], ax[l], ay[l], az[l])) {
+                ax[l - 1] = ax[l];
+                ay[l - 1] = ay[l];
+                az[l - 1] = az[l];
+            }
+        }
+        rx = ax[0];
+        ry = ay[0];
+        rz = az[0];
+    }
+    uint8_t *out = rgb + (size_t)local * 3;
+    out[0] = clamp_color(rx);
+    out[1] = clamp_color(ry);
+    out[2] = clamp_color(rz);
+}
+
+// ===========================================================================
+// Host side: scene upload and the C ABI
+// ===========================================================================
+
+static thread_local std::string g_err;
+
+static rtx_status fail(rtx_status s, const std::string &msg) {
+    g_err = msg;
+    return s;
+}
+
+#define HIP_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+struct rtx_scene {
+    int device = 0;
+    int n_cu = 256;
+    // scene (immutable after creation)
+    DNode *d_nodes = nullptr;
+    DUp *d_up = nullptr;
+    DPrim *d_prims = nullptr;
+    DMat *d_mats = nullptr;
+    uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
+    rtx_light light{};
+    // per-frame work buffers, grown on demand
+    DRec *d_recs = nullptr;
+    float4 *d_colors = nullptr;
+    uint32_t rec_cap = 0;
+    uint32_t *d_first = nullptr;
+    uint64_t pix_cap = 0;
+    uint8_t *d_rgb = nullptr; // staging for rtx_render's host output
+    uint64_t rgb_cap = 0;
+    DCounters *d_ctr = nullptr;
+    DCounters *h_ctr = nullptr; // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" uint32_t rtx_abi_version(void) { return RTX_ABI_VERSION; }
+
+extern "C" int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
+
+extern "C" void rtx_params_default(rtx_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->width = 1000;  // raytracing.h:12
+    p->height = 1000; // raytracing.h:13
+    p->n_lights = 1;  // raytracing.h:19
+    p->max_depth = 0; // raytracing.h:18
+    p->seed = 1;
+    p->acne = 0.01f; // raytracing.h:21
+    p->camera[0] = 500.f; // raytracing.h:112
+    p->camera[1] = 500.f;
+    p->camera[2] = 3000.f;
+}
+
+extern "C" uint32_t rtx_part_rows(const rtx_params *p) {
+    if (!p) return 0;
+    if (p->n_parts <= 1 || p->stripe_rows == 0) return p->height;
+    // stripes s = part, part + n_parts, ...; the last stripe may be cut short
+    uint64_t rows = 0;
+    for (uint64_t s = p->part; s * p->stripe_rows < p->height; s += p->n_parts) {
+        uint64_t lo = s * p->stripe_rows, hi = std::min<uint64_t>(lo + p->stripe_rows, p->height);
+        rows += hi - lo;
+    }
+    return (uint32_t)rows;
+}
+
+static f3 host_f3(const float *p) {
+    f3 r;
+    r.x = p[0];
+    r.y = p[1];
+    r.z = p[2];
+    return r;
+}
+
+extern "C" void rtx_scene_destroy(rtx_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_up);
+    (void)hipFree(s->d_prims);
+    (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_recs);
+    (void)hipFree(s->d_colors);
+    (void)hipFree(s->d_first);
+    (void)hipFree(s->d_rgb);
+    (void)hipFree(s->d_ctr);
+    if (s->h_ctr) (void)hipHostFree(s->h_ctr);
+    for (auto &e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, rtx_scene **out) {
+    if (!desc || !out) return fail(RTX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const uint32_t N = desc->n_nodes;
+    if ((N && !desc->nodes) || (desc->n_leaves && !desc->leaves) || (desc->n_prims && !desc->prims) ||
+        (desc->n_materials && !desc->materials))
+        return fail(RTX_ERR_INVALID, "null array with non-zero count");
+    if (desc->n_leaves > RTX_MAX_LEAVES) return fail(RTX_ERR_LIMIT, "too many leaves (limit 65535)");
+    if (desc->n_materials > RTX_MAX_MATERIALS) return fail(RTX_ERR_LIMIT, "too many materials");
+
+    // ---- validate the pre-order array, find parents and depths ----
+    std::vector<uint32_t> parent(N, RTX_NONE), depth(N, 0);
+    {
+        std::vector<uint32_t> open; // indices of the inner boxes that enclose the current one
+        std::vector<uint8_t> leaf_seen(desc->n_leaves, 0);
+        for (uint32_t n = 0; n < N; n++) {
+            while (!open.empty() && n >= desc->nodes[open.back()].skip) open.pop_back();
+            const rtx_node &nd = desc->nodes[n];
+            const uint32_t limit = open.empty() ? N : desc->nodes[open.back()].skip;
+            if (nd.skip <= n || nd.skip > limit) return fail(RTX_ERR_INVALID, "node skip index out of order");
+            parent[n] = open.empty() ? RTX_NONE : open.back();
+            depth[n] = (uint32_t)open.size();
+            if (depth[n] >= MAX_NEST) return fail(RTX_ERR_LIMIT, "boxes nested too deep (limit 23)");
+            if (nd.leaf == RTX_NONE) {
+                open.push_back(n);
+            } else {
+                if (nd.leaf >= desc->n_leaves || nd.skip != n + 1 || leaf_seen[nd.leaf])
+                    return fail(RTX_ERR_INVALID, "bad leaf reference in node");
+                leaf_seen[nd.leaf] = 1;
+                const rtx_leaf &lf = desc->leaves[nd.leaf];
+                if ((uint64_t)lf.first + lf.count > desc->n_prims)
+                    return fail(RTX_ERR_INVALID, "leaf range exceeds the primitive array");
+                if (lf.count >= 0xFFFFu) return fail(RTX_ERR_LIMIT, "leaf with more than 65534 primitives");
+            }
+        }
+    }
+    for (uint32_t k = 0; k < desc->n_prims; k++) {
+        const rtx_prim &p = desc->prims[k];
+        if (p.type != RTX_PRIM_SPHERE && p.type != RTX_PRIM_TRIANGLE)
+            return fail(RTX_ERR_INVALID, "unknown primitive type");
+        if (p.material >= desc->n_materials) return fail(RTX_ERR_INVALID, "material index out of range");
+    }
+
+    // ---- prune boxes whose subtree holds no primitive ----
+    std::vector<uint32_t> weight(N + 1, 0); // primitives in leaves with index < n
+    for (uint32_t n = 0; n < N; n++) {
+        const rtx_node &nd = desc->nodes[n];
+        weight[n + 1] = weight[n] + (nd.leaf == RTX_NONE ? 0u : desc->leaves[nd.leaf].count);
+    }
+    std::vector<uint32_t> newidx(N + 1, 0);
+    std::vector<uint8_t> keep(N, 0);
+    for (uint32_t n = 0; n < N; n++) {
+        keep[n] = weight[desc->nodes[n].skip] > weight[n];
+        newidx[n + 1] = newidx[n] + keep[n];
+    }
+    const uint32_t NK = newidx[N];
+    std::vector<DNode> nodes(NK);
+    std::vector<DUp> ups(NK);
+    for (uint32_t n = 0; n < N; n++) {
+        if (!keep[n]) continue;
+        const rtx_node &nd = desc->nodes[n];
+        DNode &o = nodes[newidx[n]];
+        memcpy(o.lb, nd.lb, sizeof(o.lb));
+        memcpy(o.rt, nd.rt, sizeof(o.rt));
+        if (nd.leaf == RTX_NONE) {
+            o.link = newidx[nd.skip];
+            o.info = RTXD_NONE;
+        } else {
+            o.link = desc->leaves[nd.leaf].first;
+            o.info = (desc->leaves[nd.leaf].count << 16) | nd.leaf;
+        }
+        ups[newidx[n]].parent = parent[n] == RTX_NONE ? RTXD_NONE : newidx[parent[n]];
+        ups[newidx[n]].depth = depth[n];
+    }
+
+    // ---- primitives: ray-independent values precomputed in the reference's
+    // operation order (host x86-64, no contraction) ----
+    std::vector<DPrim> prims(desc->n_prims);
+    for (uint32_t k = 0; k < desc->n_prims; k++) {
+        const rtx_prim &p = desc->prims[k];
+        DPrim &o = prims[k];
+        memset(&o, 0, sizeof(o));
+        o.type_mat = p.type | (p.material << 8);
+        o.id = p.id;
+        if (p.type == RTX_PRIM_TRIANGLE) {
+            const float *v0 = p.g, *v1 = p.g + 3, *v2 = p.g + 6;
+            volatile float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+            volatile float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+            // cross (vec3.h:34-41)
+            volatile float ax = e1y * e2z, bx = e1z * e2y;
+            volatile float ay = e1z * e2x, by = e1x * e2z;
+            volatile float az = e1x * e2y, bz = e1y * e2x;
+            volatile float cx = ax - bx, cy = ay - by, cz = az - bz;
+            // norm (vec3.h:10-25)
+            volatile float xx = cx * cx, yy = cy * cy, zz = cz * cz;
+            volatile float s1 = xx + yy;
+            volatile float s2 = s1 + zz;
+            const float len = sqrtf(s2);
+            o.a = host_f3(v0);
+            o.b.x = e1x, o.b.y = e1y, o.b.z = e1z;
+            o.c.x = e2x, o.c.y = e2y, o.c.z = e2z;
+            o.n.x = cx / len, o.n.y = cy / len, o.n.z = cz / len;
+        } else {
+            o.a = host_f3(p.g);
+            volatile float r2 = p.g[3] * p.g[3];
+            o.b.x = p.g[3];
+            o.b.y = r2;
+        }
+    }
+    std::vector<DMat> mats(std::max<uint32_t>(desc->n_materials, 1));
+    const float pi = atanf(1.f) * 4.f; // shade.h:3
+    for (uint32_t k = 0; k < desc->n_materials; k++) {
+        const rtx_material &m = desc->materials[k];
+        DMat &o = mats[k];
+        memset(&o, 0, sizeof(o));
+        o.ior = m.ior;
+        o.roughness = m.roughness;
+        volatile float a2 = m.roughness * m.roughness;
+        volatile float pa2 = pi * a2;
+        volatile float ratio = 1.f / m.ior;
+        volatile float r2 = ratio * ratio;
+        o.alpha2 = a2;
+        o.pi_alpha2 = pa2;
+        o.ratio2 = r2;
+        o.spec = host_f3(m.specular);
+        o.dif_pi.x = m.diffuse[0] / pi;
+        o.dif_pi.y = m.diffuse[1] / pi;
+        o.dif_pi.z = m.diffuse[2] / pi;
+    }
+
+    // ---- upload ----
+    int ndev = rtx_device_count();
+    if (ndev <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(RTX_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+
+    rtx_scene *s = new rtx_scene();
+    s->device = device;
+    s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s->n_nodes = NK;
+    s->n_prims = desc->n_prims;
+    s->n_mats = desc->n_materials;
+    s->light = desc->light;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 64);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void **)&s->d_nodes, nodes.data(), nodes.size() * sizeof(DNode));
+    if (e == hipSuccess) e = up((void **)&s->d_up, ups.data(), ups.size() * sizeof(DUp));
+    if (e == hipSuccess) e = up((void **)&s->d_prims, prims.data(), prims.size() * sizeof(DPrim));
+    if (e == hipSuccess) e = up((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(DCounters));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctr, sizeof(DCounters), hipHostMallocDefault);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
+    if (e != hipSuccess) {
+        rtx_scene_destroy(s);
+        return fail(e == hipErrorOutOfMemory ? RTX_ERR_NOMEM : RTX_ERR_HIP,
+                    std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return RTX_OK;
+}
+
+static rtx_status check_params(const rtx_scene *s, const rtx_params *p) {
+    if (!s || !p) return fail(RTX_ERR_INVALID, "null argument");
+    if (p->width == 0 || p->height == 0) return fail(RTX_ERR_INVALID, "empty frame");
+    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return fail(RTX_ERR_LIMIT, "more than 2^32 pixels");
+    if (p->n_lights > RTX_MAX_LIGHTS) return fail(RTX_ERR_LIMIT, "more than 65535 light samples");
+    if (p->max_depth != 0) return fail(RTX_ERR_INVALID, "max_depth > 0 (reflections) is not implemented");
+    if (p->n_parts > 1 && (p->stripe_rows == 0 || p->part >= p->n_parts))
+        return fail(RTX_ERR_INVALID, "bad row tiling");
+    return RTX_OK;
+}
+
+template <typename T>
+static hipError_t grow(T **ptr, uint64_t *cap, uint64_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)ptr, need * sizeof(T));
+    if (e == hipSuccess) *cap = need;
+    return e;
+}
+
+static rtx_status ensure_records(rtx_scene *s, uint64_t need) {
+    if (need <= s->rec_cap) return RTX_OK;
+    if (need > 0xFFFFFFF0ull) return fail(RTX_ERR_LIMIT, "more than 2^32 hit records in one call");
+    (void)hipFree(s->d_recs);
+    (void)hipFree(s->d_colors);
+    s->d_recs = nullptr;
+    s->d_colors = nullptr;
+    s->rec_cap = 0;
+    hipError_t e = hipMalloc((void **)&s->d_recs, need * sizeof(DRec));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_colors, need * sizeof(float4));
+    if (e != hipSuccess) return fail(RTX_ERR_NOMEM, std::string("record buffers: ") + hipGetErrorString(e));
+    s->rec_cap = (uint32_t)need;
+    return RTX_OK;
+}
+
+// Enqueue and complete one frame.  On return s->h_ctr holds the frame's counters.
+static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb, hipStream_t st,
+                               rtx_stats *stats) {
+    rtx_status rs = check_params(s, p);
+    if (rs != RTX_OK) return rs;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t rows = rtx_part_rows(p);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (rows == 0) return RTX_OK;
+    const uint64_t npix = (uint64_t)rows * p->width;
+
+    DFrame fr;
+    memset(&fr, 0, sizeof(fr));
+    fr.width = p->width;
+    fr.height = p->height;
+    fr.rows = rows;
+    fr.n_parts = (p->n_parts > 1) ? p->n_parts : 1;
+    fr.stripe_rows = (p->n_parts > 1) ? p->stripe_rows : p->height;
+    fr.part = (p->n_parts > 1) ? p->part : 0;
+    fr.n_lights = p->n_lights;
+    fr.seed = p->seed;
+    fr.acne = p->acne;
+    fr.camera = host_f3(p->camera);
+    fr.light_pos = host_f3(s->light.position);
+    fr.light_color = host_f3(s->light.color);
+    fr.scale = 1000.f / (float)p->height;
+    fr.half_width = (float)p->width * 0.5f;
+
+    if (hipError_t e = grow(&s->d_first, &s->pix_cap, npix); e != hipSuccess)
+        return fail(RTX_ERR_NOMEM, std::string("pixel buffer: ") + hipGetErrorString(e));
+    if (s->rec_cap == 0) {
+        rs = ensure_records(s, std::max<uint64_t>(npix / 2, 1u << 16));
+        if (rs != RTX_OK) return rs;
+    }
+    const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
+    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + 15) / 16);
+    const uint32_t shade_blocks = (uint32_t)s->n_cu * 8;
+    const uint32_t merge_blocks = (uint32_t)((npix + MERGE_BLOCK - 1) / MERGE_BLOCK);
+
+    for (int attempt = 0; attempt < 3; attempt++) {
+        HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
+        if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
+        trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
+                                                    s->rec_cap, s->d_first, s->d_ctr);
+        if (timing) HIP_TRY(hipEventRecord(s->ev[1], st));
+        shade_kernel<<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
+                                                          s->rec_cap, s->d_colors, s->d_ctr);
+        if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
+        merge_kernel<<<merge_blocks, MERGE_BLOCK, 0, st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
+                                                          s->d_colors, s->d_first, d_rgb);
+        if (timing) HIP_TRY(hipEventRecord(s->ev[3], st));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (s->h_ctr->n_recs <= s->rec_cap) break;
+        // more hits than the record buffer holds: grow it and render again
+        if (attempt == 2) return fail(RTX_ERR_HIP, "record buffer overflow persisted");
+        rs = ensure_records(s, (uint64_t)s->h_ctr->n_recs + s->h_ctr->n_recs / 8 + 1024);
+        if (rs != RTX_OK) return rs;
+    }
+    if (stats) {
+        stats->primary_rays = npix;
+        stats->hits = s->h_ctr->n_recs;
+        stats->shadow_rays = (uint64_t)s->h_ctr->n_recs * p->n_lights;
+        stats->shadow_tests = (uint64_t)s->h_ctr->leaf_prims * p->n_lights;
+        if (timing) {
+            for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
+            HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[3], s->ev[0], s->ev[3]));
+        }
+    }
+    return RTX_OK;
+}
+
+extern "C" rtx_status rtx_render_device(rtx_scene *s, const rtx_params *p, void *d_rgb, void *hip_stream,
+                                        rtx_stats *stats) {
+    if (!d_rgb) return fail(RTX_ERR_INVALID, "null output");
+    return render_frame(s, p, (uint8_t *)d_rgb, (hipStream_t)hip_stream, stats);
+}
+
+static rtx_status render_to_staging(rtx_scene *s, const rtx_params *p, rtx_stats *stats) {
+    rtx_status rs = check_params(s, p);
+    if (rs != RTX_OK) return rs;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint64_t bytes = (uint64_t)rtx_part_rows(p) * p->width * 3;
+    if (hipError_t e = grow(&s->d_rgb, &s->rgb_cap, std::max<uint64_t>(bytes, 64)); e != hipSuccess)
+        return fail(RTX_ERR_NOMEM, std::string("output staging: ") + hipGetErrorString(e));
+    return render_frame(s, p, s->d_rgb, nullptr, stats);
+}
+
+extern "C" rtx_status rtx_render(rtx_scene *s, const rtx_params *p, uint8_t *rgb_host, rtx_stats *stats) {
+    if (!rgb_host) return fail(RTX_ERR_INVALID, "null output");
+    rtx_status rs = render_to_staging(s, p, stats);
+    if (rs != RTX_OK) return rs;
+    const uint64_t bytes = (uint64_t)rtx_part_rows(p) * p->width * 3;
+    if (bytes) HIP_TRY(hipMemcpy(rgb_host, s->d_rgb, bytes, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+extern "C" rtx_status rtx_render_hits(rtx_scene *s, const rtx_params *p, rtx_hit *hits, uint64_t capacity,
+                                      uint64_t *n_hits, uint8_t *rgb_host) {
+    if (!n_hits) return fail(RTX_ERR_INVALID, "null n_hits");
+    rtx_status rs = render_to_staging(s, p, nullptr);
+    if (rs != RTX_OK) return rs;
+    const uint64_t bytes = (uint64_t)rtx_part_rows(p) * p->width * 3;
+    if (rgb_host && bytes) HIP_TRY(hipMemcpy(rgb_host, s->d_rgb, bytes, hipMemcpyDeviceToHost));
+    const uint64_t n = rtx_part_rows(p) ? s->h_ctr->n_recs : 0;
+    *n_hits = n;
+    if (!hits || n == 0) return RTX_OK;
+    std::vector<DRec> recs(n);
+    std::vector<float4> cols(n);
+    HIP_TRY(hipMemcpy(recs.data(), s->d_recs, n * sizeof(DRec), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cols.data(), s->d_colors, n * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order(n);
+    for (uint64_t k = 0; k < n; k++) order[k] = (uint32_t)k;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (recs[a].pixel != recs[b].pixel) return recs[a].pixel < recs[b].pixel;
+        return recs[a].ordinal < recs[b].ordinal;
+    });
+    for (uint64_t k = 0; k < n && k < capacity; k++) {
+        const DRec &r = recs[order[k]];
+        const float4 &c = cols[order[k]];
+        rtx_hit &h = hits[k];
+        h.pixel = r.pixel;
+        h.ordinal = r.ordinal;
+        h.leaf = r.leaf;
+        h.prim = r.prim;
+        h.t = r.t;
+        h.color[0] = c.x;
+        h.color[1] = c.y;
+        h.color[2] = c.z;
+    }
+    return RTX_OK;
+}

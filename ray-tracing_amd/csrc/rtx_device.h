@@ -1,0 +1,218 @@
+// Device-side data layout and arithmetic shared by the kernels of rtx_amd.hip.
+//
+// Everything here is binary32 and is written so that, compiled with
+// -ffp-contract=off (no fused multiply-add) and the default correctly rounded
+// division and square root, each function returns bit for bit what the
+// reference's C++ returns on x86-64 (vec3.h, intersect.h; g++ without -march:
+// SSE scalar arithmetic, no contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RTXD_NONE 0xFFFFFFFFu
+
+struct f3 {
+    float x, y, z;
+};
+
+// One box of the pruned pre-order array (32 B).  Boxes whose subtree holds no
+// primitive are left out, which cannot change a frame: an empty leaf never
+// yields a hit and a hit-free subtree folds to black (raytracing.h:69, :76).
+//   inner box: link = index of the next box once this subtree is done or
+//              missed; info = RTXD_NONE
+//   leaf box:  link = first primitive reference of the leaf (the next box is
+//              simply index + 1); info = count << 16 | scene-wide leaf number
+struct DNode {
+    float lb[3];
+    float rt[3];
+    uint32_t link;
+    uint32_t info;
+};
+
+// Parent (index into the same array, RTXD_NONE at top level) and nesting
+// depth (0 at top level) of a box; the colour merge needs them.
+struct DUp {
+    uint32_t parent;
+    uint32_t depth;
+};
+
+struct DLeaf {
+    uint32_t first;
+    uint32_t count;
+};
+
+// One leaf primitive reference, 64 B, so that a wave that walks a leaf with a
+// uniform index fetches it with one 16-dword scalar load.
+//   triangle: a = v0, b = edge1 = v1 - v0, c = edge2 = v2 - v0 (intersect.h:33-34),
+//             n = normalize(cross(edge1, edge2)) (intersect.h:59)
+//   sphere:   a = centre, b.x = radius, b.y = radius * radius (intersect.h:6)
+// The derived values are computed once on the host with the reference's
+// operation order; they depend on the primitive only, not on the ray.
+struct __attribute__((aligned(64))) DPrim {
+    f3 a, b, c, n;
+    uint32_t type_mat; // type | material << 8
+    uint32_t id;
+    uint32_t pad[2];
+};
+
+// Material with the ray-independent subexpressions of shade.h folded in.
+struct __attribute__((aligned(16))) DMat {
+    float ior;
+    float roughness;
+    float alpha2;    // roughness * roughness            (shade.h:14)
+    float pi_alpha2; // PI * alpha2                      (shade.h:15)
+    float ratio2;    // (1 / ior) * (1 / ior)            (shade.h:25-26)
+    f3 spec;
+    f3 dif_pi; // diffuseColor / PI                 (shade.h:70)
+    float pad;
+};
+
+// One (pixel, leaf) hit produced by the trace kernel and consumed by the
+// shading and merge kernels (64 B).
+struct __attribute__((aligned(16))) DRec {
+    uint32_t pixel; // global pixel index j * width + i
+    uint32_t node;  // index of the leaf's box in the pruned array
+    uint32_t prim;  // global primitive id
+    float t;
+    float px, py, pz; // hit position (intersect.h:20, :58)
+    uint32_t mat;
+    float nx, ny, nz; // normal
+    uint32_t next;    // next record of the same pixel, visit order
+    uint32_t leaf;
+    uint32_t first, count; // the leaf's primitive range
+    uint32_t ordinal;
+};
+
+struct DFrame {
+    uint32_t width, height;
+    uint32_t rows; // rows rendered by this call
+    uint32_t stripe_rows, n_parts, part;
+    uint32_t n_lights, seed;
+    float acne;
+    f3 camera;
+    f3 light_pos;
+    f3 light_color;
+    float scale; // 1000 / height
+    float half_width;
+};
+
+// Counters of one frame (device memory, zeroed before the trace kernel).
+struct DCounters {
+    uint32_t n_recs;     // records appended (may exceed the capacity)
+    uint32_t queue_head; // next record the shading kernel hands out
+    unsigned long long leaf_prims; // sum of the leaf sizes over all records
+};
+
+// ---- vec3.h -----------------------------------------------------------------
+__device__ __forceinline__ f3 f3_make(float x, float y, float z) {
+    f3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+__device__ __forceinline__ f3 f3_add(f3 a, f3 b) { return f3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 f3_sub(f3 a, f3 b) { return f3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 f3_mul(f3 a, f3 b) { return f3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 f3_scale(f3 a, float s) { return f3_make(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 f3_div(f3 a, float s) { return f3_make(a.x / s, a.y / s, a.z / s); }
+// vec3.h:10-13: evaluated left to right
+__device__ __forceinline__ float f3_dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// vec3.h:28-31: three divisions by the norm
+__device__ __forceinline__ f3 f3_normalize(f3 a) { return f3_div(a, __builtin_sqrtf(f3_dot(a, a))); }
+// vec3.h:34-41
+__device__ __forceinline__ f3 f3_cross(f3 u, f3 v) {
+    return f3_make(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+// std::min / std::max as libstdc++ defines them; they differ from fminf /
+// fmaxf when an operand is NaN, which the slab test produces for rays parallel
+// to an axis (0 * inf).
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+
+// ---- intersect.h -------------------------------------------------------------
+// intersect.h:28-67 with the ray-independent edges precomputed.
+__device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &t) {
+    const float eps = 0.0000001f;
+    f3 h = f3_cross(d, e2);
+    float a = f3_dot(e1, h);
+    if (a > -eps && a < eps) return false;
+    float f = 1.f / a;
+    f3 s = f3_sub(o, v0);
+    float u = f * f3_dot(s, h);
+    if (u < 0.f || u > 1.f) return false;
+    f3 q = f3_cross(s, e1);
+    float v = f * f3_dot(d, q);
+    if (v < 0.f || u + v > 1.f) return false;
+    t = f * f3_dot(e2, q);
+    return t > eps;
+}
+
+// intersect.h:1-18 (distance only)
+__device__ __forceinline__ bool sph_hit(f3 o, f3 d, f3 c, float r2, float &t) {
+    f3 pos = f3_sub(o, c);
+    float a = 1.f;
+    float b = 2.f * f3_dot(d, pos);
+    float cc = f3_dot(pos, pos) - r2;
+    float delta = b * b - 4.f * a * cc;
+    if (delta <= 0.f) return false;
+    float sq = __builtin_sqrtf(delta);
+    float t1 = (-b - sq) / (2.f * a);
+    float t2 = (-b + sq) / (2.f * a);
+    t = t1 > 0.f ? t1 : t2 > 0.f ? t2 : -1.f;
+    return t > 0.f;
+}
+
+// intersect.h:69-93 with 1 / direction hoisted out of the per-box call (the
+// reference recomputes the same three quotients at every box).
+__device__ __forceinline__ bool box_hit(f3 o, f3 inv, const float *lb, const float *rt) {
+    float t1 = (lb[0] - o.x) * inv.x;
+    float t2 = (rt[0] - o.x) * inv.x;
+    float t3 = (lb[1] - o.y) * inv.y;
+    float t4 = (rt[1] - o.y) * inv.y;
+    float t5 = (lb[2] - o.z) * inv.z;
+    float t6 = (rt[2] - o.z) * inv.z;
+    float tmin = std_max(std_max(std_min(t1, t2), std_min(t3, t4)), std_min(t5, t6));
+    float tmax = std_min(std_min(std_max(t1, t2), std_max(t3, t4)), std_max(t5, t6));
+    if (tmax < 0.f) return false;
+    if (tmin > tmax) return false;
+    return true;
+}
+
+// utils.h:12-17
+__device__ __forceinline__ bool out_of_scene(f3 c) {
+    return c.x < 0.f || c.x > 1000.f || c.y < 0.f || c.y > 1000.f || c.z < 0.f || c.z > 1000.f;
+}
+
+// ---- light sampler -------------------------------------------------------------
+// Philox-2x32-10, key = seed, counter = (pixel, leaf << 16 | sample); each
+// output word is mapped to 0..500 by a 32x32 -> high-32 multiply with 501.
+__device__ __forceinline__ void light_sample(uint32_t seed, uint32_t pixel, uint32_t leaf,
+                                             uint32_t k, float &lx, float &ly) {
+    uint32_t c0 = pixel, c1 = (leaf << 16) | k, key = seed;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        unsigned long long prod = (unsigned long long)0xD256D193u * c0;
+        uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += 0x9E3779B9u;
+    }
+    lx = 250.f + (float)__umulhi(c0, 501u); // raytracing.h:38
+    ly = 250.f + (float)__umulhi(c1, 501u); // raytracing.h:39
+}
+
+// ---- primary ray (raytracing.h:119-121) ----------------------------------------
+// World units are the pixels of a 1000-row image; at 1000 x 1000 the origin is
+// exactly (i, j, 1000).
+__device__ __forceinline__ void primary_ray(const DFrame &fr, uint32_t i, uint32_t j, f3 &o, f3 &d) {
+    o = f3_make(500.f + ((float)i - fr.half_width) * fr.scale, (float)j * fr.scale, 1000.f);
+    d = f3_normalize(f3_sub(o, fr.camera));
+}
+
+// Global row of local row r of this part (rows are dealt to parts in stripes).
+__device__ __forceinline__ uint32_t part_row(const DFrame &fr, uint32_t r) {
+    if (fr.n_parts <= 1) return r;
+    uint32_t s = r / fr.stripe_rows;
+    return (s * fr.n_parts + fr.part) * fr.stripe_rows + (r - s * fr.stripe_rows);
+}
