@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on 1..8 MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+A step is one frame of the workload: the image rows are dealt to the N ranks in stripes
+(one process per GPU, scene replicated), every rank renders its stripes through the C
+ABI (rtx_render_device) into device memory, and the stripes are gathered to rank 0 over
+RCCL.  The scene is uploaded once before the timed region.  Rank 0 prints one JSON line:
+
+  value     Mrays/s = (primary rays + shadow rays) of the whole frame / frame time, both
+            ray counts as counted by the renderer (pixels; hit records x light samples)
+  roofline  the shadow/shade kernel (the dominant one): algorithmic FLOP of one launch
+            divided by its HIP-event duration, against the FP32 vector peak
+  cpu_baseline  the CPU oracle (a port of the reference's renderer with the same light
+            sampler) timed on this host's cores on a bounded sample of the same frame
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs -> (scene, width, height, light samples)
+WORKLOADS = {
+    "buddha": ("buddha", 3840, 2160, 500,
+               "buddha.off, box depth 10, 3840x2160, 500 light samples (BASELINE configs[3], the north-star target)"),
+    "bunny": ("bunny", 1920, 1080, 100,
+              "bunny.off, box depth 10, 1920x1080, 100 light samples (BASELINE configs[1])"),
+    "dino_spheres": ("dino_spheres", 1920, 1080, 500,
+                     "dino.off + sphere, box depth 10, 1920x1080, 500 light samples (BASELINE configs[2])"),
+    "multi": ("multi", 3840, 2160, 1000,
+              "bunny + dino + buddha + sphere, 3840x2160, 1000 light samples (BASELINE configs[4])"),
+    "default": ("default", 1000, 1000, 1, "scene.h as committed, 1000x1000, 1 light sample"),
+}
+STRIPE_ROWS = 8
+
+# Algorithmic work per unit (FLOP; a multiply and an add count one each, a division or
+# a square root one).
+FLOP_PER_PRIM_TEST = 51      # Moeller-Trumbore run to completion (intersect.h:28-67)
+FLOP_PER_SHADOW_RAY = 16     # origin step, direction, normalisation (raytracing.h:40-43)
+FLOP_PER_SHADED_SAMPLE = 92  # shade(): ~80 + exp + 3 sqrt + 8 div (shade.h:80-90)
+BYTES_PER_PRIM_TEST = 36     # nine floats per ray-triangle test, as if fetched each time
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X FP32 vector peak (an FMA counted as 2 FLOP)
+PEAK_FP32_UNFUSED_TFLOPS = 78.6   # the same issue rate without FMA contraction
+PEAK_HBM_GBS = 8000.0
+
+
+def build_scene(rtx, scenes, name):
+    """Scene description through the product's host layer (C++), not the oracle."""
+    host = importlib.import_module("ray-tracing_amd.host_py")
+    builder = host.HostBuilder(10)
+    desc = scenes.assemble(builder, name)
+    return builder, desc
+
+
+def cpu_baseline(scenes, name, w, h, nl):
+    """The CPU oracle on this host's cores, on every second stripe of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    b = oracle_py.OracleBuilder(10)
+    d = scenes.assemble(b, name)
+    p = oracle_py.capi.default_params(w, h, nl, 1)
+    sample = "every 2nd stripe of %d rows (half the frame)" % STRIPE_ROWS
+    p.stripe_rows, p.n_parts, p.part = STRIPE_ROWS, 2, 0
+    # keep it bounded: thin the sample until a pilot says it fits in ~20 s
+    pilot = oracle_py.capi.default_params(w, h, nl, 1)
+    pilot.stripe_rows, pilot.n_parts, pilot.part = STRIPE_ROWS, 32, 15
+    t0 = time.perf_counter()
+    oracle_py.render(d, pilot, want_hits=False, want_rgb=False)
+    t_pilot = time.perf_counter() - t0
+    if t_pilot * 16 > 25.0:
+        parts = 32 if t_pilot > 12.0 else max(2, int(round(t_pilot * 32 / 20.0)))
+        p.n_parts, p.part = parts, parts // 2
+        sample = "one stripe of %d rows in every %d" % (STRIPE_ROWS, parts)
+    t0 = time.perf_counter()
+    _, _, _, st = oracle_py.render(d, p, want_hits=False, want_rgb=False)
+    dt = time.perf_counter() - t0
+    rays = st.primary_rays + st.shadow_rays
+    threads = oracle_py.oracle().orc_max_threads()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%s of %s, %d rays in %.2f s" % (sample, name, rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="buddha", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with "
+                             "python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rtx = importlib.import_module("ray-tracing_amd")
+    scenes = importlib.import_module("ray-tracing_amd.scenes")
+    name, w, h, nl, label = WORKLOADS[args.workload]
+
+    builder, desc = build_scene(rtx, scenes, name)
+    scene = rtx.Scene(desc, local_rank)            # uploaded once, resident in HBM
+    p = rtx.default_params(w, h, nl, 1)
+    p.flags |= rtx.capi.RTX_FLAG_TIMING
+    if world > 1:
+        p.stripe_rows, p.n_parts, p.part = STRIPE_ROWS, world, rank
+    rows = rtx.part_rows(p)
+    max_rows = rows
+    if world > 1:
+        q = rtx.default_params(w, h, nl, 1)
+        q.stripe_rows, q.n_parts, q.part = STRIPE_ROWS, world, 0
+        max_rows = rtx.part_rows(q)               # part 0 has the most rows
+    tile = torch.zeros((max_rows, w, 3), dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = scene.render_device(p, tile.data_ptr(), stream)
+        if world > 1:
+            dist.gather(tile, gathered, dst=0)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    shade_ms = trace_ms = merge_ms = 0.0
+    st = None
+    for _ in range(args.steps):
+        st = step()
+        trace_ms += st.kernel_ms[0]
+        shade_ms += st.kernel_ms[1]
+        merge_ms += st.kernel_ms[2]
+    fence()
+    elapsed = time.perf_counter() - t0
+    counts = torch.tensor([elapsed, float(st.primary_rays), float(st.shadow_rays), float(st.shadow_tests),
+                           float(st.hits), float(st.lit_samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = counts.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        counts[0] = mx[0]
+    elapsed, primary, shadow, tests, hits, lit = [float(x) for x in counts.tolist()]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        rays = primary + shadow
+        # roofline of the shadow/shade kernel on this rank (rank 0's share of the frame)
+        k = args.steps
+        shade_avg_ms = shade_ms / k
+        flop = (st.shadow_tests * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
+                st.lit_samples * FLOP_PER_SHADED_SAMPLE)
+        achieved = flop / (shade_avg_ms * 1e-3) / 1e12 if shade_avg_ms > 0 else 0.0
+        alg_bytes = st.shadow_tests * BYTES_PER_PRIM_TEST
+        out = {
+            "metric": "Mrays/s (primary+shadow)",
+            "value": rays / (elapsed / args.steps) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "reference mesh geometry (%s), counter-based synthetic light samples, seed 1" % name,
+            "config": {"workload": label, "stripe_rows": STRIPE_ROWS,
+                       "parallelism": "row stripes dealt to %d GPU(s), scene replicated, RCCL gather" % world,
+                       "primary_rays": int(primary), "shadow_rays": int(shadow), "hit_records": int(hits)},
+            "roofline": {
+                "kernel": "shade_kernel", "bound": "valu",
+                "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
+                "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
+                "traffic": None,
+                "launch_ms": shade_avg_ms,
+                "algorithmic_flop_per_launch": flop,
+                "hbm": {"bound": "hbm", "achieved": alg_bytes / (shade_avg_ms * 1e-3) / 1e9 if shade_avg_ms > 0 else 0.0,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": (alg_bytes / (shade_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if shade_avg_ms > 0 else 0.0,
+                        "note": "algorithmic bytes as if every test fetched its triangle; the scene is cache resident"},
+            },
+            "kernel_ms": {"trace": trace_ms / k, "shade": shade_avg_ms, "merge": merge_ms / k},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scenes, name, w, h, nl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,8 @@ typedef struct rtx_stats {
     uint64_t shadow_rays;   /* hits * n_lights */
     uint64_t shadow_tests;  /* primitive tests done for shadow rays:
                                n_lights * sum over hits of the leaf's size */
+    uint64_t lit_samples;   /* shadow rays that reached the light, i.e. shade()
+                               evaluations (raytracing.h:45-48) */
     float kernel_ms[4];     /* trace, shadow+shade, merge, total on the stream
                                (only with RTX_FLAG_TIMING) */
 } rtx_stats;

@@ -1,0 +1,140 @@
+// rtx_dropin.hpp - the reference's C++ scene / mesh / render entry points, backed by the
+// MI355X library (include/rtx.h).
+//
+// A program written against the reference includes "raytracing.h" and calls
+//     bool init_scene(Light &, Boxs &);      (scene.h:4)
+//     bool render_image(Light &, Boxs &);    (raytracing.h:100)
+// and, when it assembles its own scene,
+//     bool parse(std::string, Mesh &);       (meshs.h:60)
+//     void create_mesh(Mesh &, Boxs &);      (meshs.h:1)
+//     void create_boxs(Boxs &);              (bvh.h:5)
+// on the plain structs of structs.h / vec3.h.  Including this header instead and
+// linking librtx_host.so + librtx_amd.so keeps those names, argument meanings and the
+// bool (true = success) error convention; the pixel loop runs on the GPU.
+//
+// The data types below have the reference's member names and layout (they are the API);
+// the functions are implemented from scratch in ray-tracing_amd/host/.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rtx.h"
+
+// ---- vec3.h ---------------------------------------------------------------------------
+template <typename T>
+struct Vec3 {
+    T x, y, z;
+};
+using Vec3F = Vec3<float>;
+
+// ---- structs.h --------------------------------------------------------------------------
+enum Type { SPHERE = 1, TRIANGLE };
+
+struct Material {
+    float IOR;
+    float roughness;
+    Vec3F specularColor;
+    Vec3F diffuseColor;
+};
+
+struct Object {
+    Type type;
+    union {
+        struct {
+            Vec3F position;
+            float radius;
+        } sphere;
+        struct {
+            Vec3F v0, v1, v2;
+        } triangle;
+    };
+    Material material;
+};
+
+struct Ray {
+    Vec3F origin;
+    Vec3F direction;
+    int depth;
+};
+
+struct Light {
+    Vec3F position;
+    Vec3F color;
+};
+
+struct Mesh {
+    Vec3F position;
+    float taille;
+    Material material;
+    std::vector<Vec3F> vertices;
+    std::vector<Vec3F> facades; // vertex indices kept as floats, as the reference does
+};
+
+struct Box {
+    Vec3F lb, rt;
+    std::vector<Box> boxs;
+    int depth;
+    std::vector<Object> objects;
+};
+
+typedef std::vector<Box> Boxs;
+typedef std::vector<Object> Objects;
+
+// ---- settings the reference fixes with #define ---------------------------------------------
+#ifndef DEPTH_BOX
+#define DEPTH_BOX 10 // bvh.h:3
+#endif
+
+namespace rtx_host {
+
+// Run-time counterparts of WIDTH, HEIGHT, NB_LIGHTS (raytracing.h:12-19), the camera
+// (raytracing.h:112), acne (raytracing.h:21) and DEPTH_BOX; the defaults are the
+// reference's values.  render_image() and create_boxs() read them.
+struct Settings {
+    rtx_params frame;               // width, height, n_lights, seed, acne, camera
+    int box_depth = DEPTH_BOX;      // depth at which create_boxs stops splitting
+    int device = 0;                 // HIP device used by render_image
+    std::string output = "out.png"; // raytracing.h:140
+    bool quiet = false;             // suppress the progress / "saved" messages
+    Settings();
+};
+Settings &settings();
+
+// Flattened form of a `Boxs` tree (what rtx_scene_create takes).  The arrays live in
+// the object; desc() points into them.
+struct FlatScene {
+    std::vector<rtx_node> nodes;
+    std::vector<rtx_leaf> leaves;
+    std::vector<rtx_prim> prims;
+    std::vector<rtx_material> materials;
+    rtx_light light;
+    rtx_scene_desc desc() const;
+};
+
+// Walks `boxs` in the order trace_ray_boxs does (raytracing.h:74-98).  Primitive ids
+// are positions in the concatenated top-level object lists; `materials` may be
+// pre-seeded to fix the material numbering.  Returns false (and a message in *error)
+// if the tree cannot be expressed (more than 65535 leaves, ...).
+bool flatten(const Light &light, const Boxs &boxs, int box_depth, FlatScene &out, std::string *error);
+
+// Render into memory instead of a file: rgb receives width * height * 3 bytes, pixel
+// (i, j) at (j * width + i) * 3.  Returns false on failure (message in *error).
+bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t> &rgb,
+                      rtx_stats *stats, std::string *error);
+
+// Minimal PNG (8-bit RGB, stored deflate blocks) and PPM writers.  Row j = 0 of `rgb`
+// is written as the BOTTOM scanline, as FreeImage_SetPixelColor places it
+// (raytracing.h:130).
+bool write_png(const std::string &path, const uint8_t *rgb, uint32_t width, uint32_t height);
+bool write_ppm(const std::string &path, const uint8_t *rgb, uint32_t width, uint32_t height);
+
+} // namespace rtx_host
+
+// ---- the reference's entry points ---------------------------------------------------------
+bool parse(std::string filename, Mesh &mesh);
+void create_mesh(Mesh &mesh, Boxs &boxs);
+void create_boxs(Boxs &boxs);
+bool init_scene(Light &light, Boxs &boxs);
+bool render_image(Light &light, Boxs &boxs);

@@ -292,7 +292,7 @@ static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pi
         lpos.y = xy[1];
         pos = v3_add(pos, v3_scale(hit.nrm, p->acne)); /* accumulates, raytracing.h:40 */
         v3 sd = v3_normalize(v3_sub(lpos, pos));
-        isect sh;
+        isect sh = {0.f, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         int occ = nearest_in_leaf(pos, sd, pr, lf->count, &sh, &st->shadow_prim_tests);
         st->shadow_rays++;
         if (occ < 0 || out_of_scene(sh.pos)) {

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
+        uint32_t lit = 0;
         for (uint32_t base = 0; base < fr.n_lights; base += 64) {
             if (lane < 3) {
 #pragma unroll
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
                 if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
                     const f3 c = shade(nrm, view, sd, fr.light_color, mat);
                     acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
+                    lit++;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -269,8 +271,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
             acc.x += __shfl_xor(acc.x, off);
             acc.y += __shfl_xor(acc.y, off);
             acc.z += __shfl_xor(acc.z, off);
+            lit += __shfl_xor(lit, off);
         }
-        if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (lane == 0) {
+            colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            atomicAdd(&ctr->lit, (unsigned long long)lit);
+        }
     }
 }
 
@@ -728,6 +734,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         stats->hits = s->h_ctr->n_recs;
         stats->shadow_rays = (uint64_t)s->h_ctr->n_recs * p->n_lights;
         stats->shadow_tests = (uint64_t)s->h_ctr->leaf_prims * p->n_lights;
+        stats->lit_samples = s->h_ctr->lit;
         if (timing) {
             for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
             HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[3], s->ev[0], s->ev[3]));

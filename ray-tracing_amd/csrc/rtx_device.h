@@ -101,6 +101,7 @@ struct DCounters {
     uint32_t n_recs;     // records appended (may exceed the capacity)
     uint32_t queue_head; // next record the shading kernel hands out
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
+    unsigned long long lit;        // light samples that were not occluded
 };
 
 // ---- vec3.h -----------------------------------------------------------------

@@ -1,0 +1,123 @@
+"""The C++ host layer (include/rtx_dropin.hpp: parse, create_mesh, create_boxs,
+init_scene, flatten) against the CPU oracle's scene assembly and the structure fixtures
+that come from the reference's own functions.  Bit for bit."""
+import hashlib
+import importlib
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def host():
+    return importlib.import_module("ray-tracing_amd.host_py")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("cfg", ["default", "spheres", "bunny", "dino_spheres", "buddha", "multi"])
+def test_host_scene_equals_reference_structure(op, scenes, host, golden_dir, cfg):
+    with open(os.path.join(golden_dir, "structure.json")) as f:
+        want = json.load(f)[cfg]
+    hb = host.HostBuilder(10)
+    d = scenes.assemble(hb, cfg)
+    assert (d.n_nodes, d.n_leaves, d.n_prims, d.n_materials) == (
+        want["n_nodes"], want["n_leaves"], want["n_prims"], want["n_materials"])
+    for k, v in op.desc_arrays(d).items():
+        assert sha(v) == want["sha256_" + k], k
+
+
+@pytest.mark.parametrize("depth", [0, 2, 7, 12])
+def test_host_scene_equals_oracle_at_other_depths(op, scenes, host, depth):
+    hb = host.HostBuilder(depth)
+    a = op.desc_arrays(scenes.assemble(hb, "dino_spheres"))
+    ob = op.OracleBuilder(depth)
+    b = op.desc_arrays(scenes.assemble(ob, "dino_spheres"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def _write_off(path, verts, faces, header="OFF", counts=None):
+    with open(path, "w") as f:
+        f.write("%s\n%s\n" % (header, counts or "%d %d 0" % (len(verts), len(faces))))
+        for v in verts:
+            f.write("%.9g %.9g %.9g\n" % tuple(float(x) for x in v))
+        for t in faces:
+            f.write("3 %d %d %d \n" % tuple(int(x) for x in t))
+
+
+def test_parse_round_trip_and_errors(op, scenes, host, tmp_path):
+    verts, faces = scenes.load_mesh("bunny")
+    path = str(tmp_path / "bunny.off")
+    _write_off(path, verts, faces)
+    rc, v, f = host.parse_off(path)
+    assert rc == 0
+    assert np.array_equal(v.view(np.uint32), verts.view(np.uint32)) and np.array_equal(f, faces)
+    bad = str(tmp_path / "bad.off")
+    _write_off(bad, verts[:3], faces[:0], header="OFF ")
+    assert host.parse_off(bad)[0] == 1                       # meshs.h:79-83
+    assert host.parse_off(str(tmp_path / "nope.off"))[0] == 1  # unopened stream reads as "not OFF"
+
+
+def test_parse_keeps_the_reference_face_count_quirk(op, host, tmp_path):
+    """meshs.h:88-91 reads the face count from (digits of the vertex count + 1)
+    characters: '8 12 0' yields 1 face, in the host layer as in the oracle."""
+    verts = np.arange(24, dtype=np.float32).reshape(8, 3)
+    faces = np.array([[k % 8, (k + 1) % 8, (k + 2) % 8] for k in range(12)], np.uint32)
+    path = str(tmp_path / "cube.off")
+    _write_off(path, verts, faces)
+    rc_h, v_h, f_h = host.parse_off(path)
+    rc_o, v_o, f_o = op.parse_off(path)
+    assert rc_h == rc_o == 0
+    assert len(f_h) == len(f_o) == 1 and np.array_equal(f_h, f_o) and np.array_equal(v_h, v_o)
+
+
+def test_init_scene_from_files(op, scenes, host, golden_dir, tmp_path):
+    """init_scene() (scene.h:4-108) reading meshs/*.off from the working directory."""
+    os.makedirs(tmp_path / "meshs")
+    for name in ("bunny", "dino"):
+        v, f = scenes.load_mesh(name)
+        _write_off(str(tmp_path / "meshs" / (name + ".off")), v, f)
+    hb = host.HostBuilder(10)
+    hb.init_scene(str(tmp_path))
+    d = hb.build()
+    with open(os.path.join(golden_dir, "structure.json")) as f:
+        want = json.load(f)["init_scene"]
+    for k, v in op.desc_arrays(d).items():
+        assert sha(v) == want["sha256_" + k], k
+
+
+def test_init_scene_fails_without_meshes(host, tmp_path):
+    hb = host.HostBuilder(10)
+    with pytest.raises(RuntimeError):
+        hb.init_scene(str(tmp_path))
+
+
+def test_png_writer(host, tmp_path):
+    """8-bit RGB PNG; row j = 0 is the bottom scanline (FreeImage's convention)."""
+    rgb = np.random.default_rng(0).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = str(tmp_path / "x.png")
+    host.write_png(path, rgb)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(tag + body) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (53, 37, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 3)
+    assert (raw[:, 0] == 0).all()
+    assert np.array_equal(raw[:, 1:].reshape(37, 53, 3), rgb[::-1])
