@@ -201,11 +201,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
     const float nl = (float)fr.n_lights;
 
+    // Records are handed out through eight queues (record i is in queue i & 7).  A wave
+    // starts on the queue of its block (blocks b and b + 8 tend to share an XCD, hence
+    // an L2) and moves on to the next one when its queue is drained; queues only ever
+    // drain, so after eight empty answers every wave is done.
+    uint32_t q = blockIdx.x & 7, empty = 0, lit_total = 0;
     for (;;) {
-        uint32_t ridx = 0;
-        if (lane == 0) ridx = atomicAdd(&ctr->queue_head, 1u);
-        ridx = __builtin_amdgcn_readfirstlane(ridx);
-        if (ridx >= n_recs) break; // every wave reaches this once the queue is drained
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&ctr->head[q].next, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const uint32_t ridx = k * 8 + q;
+        if (ridx >= n_recs) {
+            if (++empty == 8) break; // every wave reaches this once all queues are drained
+            q = (q + 1) & 7;
+            continue;
+        }
 
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, first = rc.first, count = rc.count;
@@ -273,11 +283,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
             acc.z += __shfl_xor(acc.z, off);
             lit += __shfl_xor(lit, off);
         }
-        if (lane == 0) {
-            colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
-            atomicAdd(&ctr->lit, (unsigned long long)lit);
-        }
+        if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        lit_total += lit;
     }
+    if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
 }
 
 // ---- merge -----------------------------------------------------------------------

@@ -98,10 +98,18 @@ struct DFrame {
 
 // Counters of one frame (device memory, zeroed before the trace kernel).
 struct DCounters {
-    uint32_t n_recs;     // records appended (may exceed the capacity)
-    uint32_t queue_head; // next record the shading kernel hands out
+    uint32_t n_recs;               // records appended (may exceed the capacity)
+    uint32_t pad0;
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
     unsigned long long lit;        // light samples that were not occluded
+    uint32_t pad1[26];
+    // Work queue of the shading kernel, sharded eight ways so that the returning
+    // atomic on one word (about 90 M/s chip-wide) does not pace the kernel: record i
+    // belongs to shard i & 7; each head sits on a 128-byte line of its own.
+    struct {
+        uint32_t next;
+        uint32_t pad[31];
+    } head[8];
 };
 
 // ---- vec3.h -----------------------------------------------------------------

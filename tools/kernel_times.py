@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event times of a workload, frame by frame (GPU box).
+usage: kernel_times.py [workload ...] [--frames N]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rtx = importlib.import_module("ray-tracing_amd")
+scenes = importlib.import_module("ray-tracing_amd.scenes")
+host = importlib.import_module("ray-tracing_amd.host_py")
+import bench  # noqa: E402
+
+frames = 8
+names = []
+args = sys.argv[1:]
+while args:
+    a = args.pop(0)
+    if a == "--frames":
+        frames = int(args.pop(0))
+    else:
+        names.append(a)
+for name in names or ["bunny", "buddha"]:
+    cfg, w, h, nl, _ = bench.WORKLOADS[name]
+    b = host.HostBuilder(10)
+    d = scenes.assemble(b, cfg)
+    sc = rtx.Scene(d)
+    import numpy as np
+    out = []
+    for k in range(frames):
+        p = rtx.default_params(w, h, nl, 1)
+        rgb, st = sc.render(p, timing=True)
+        out.append(list(st.kernel_ms))
+    a = np.array(out)
+    print("%-13s %dx%d N=%d hits=%d tests=%.3g lit=%d" % (name, w, h, nl, st.hits, st.shadow_tests, st.lit_samples))
+    print("   trace ms ", " ".join("%.3f" % x for x in a[:, 0]))
+    print("   shade ms ", " ".join("%.3f" % x for x in a[:, 1]))
+    print("   merge ms ", " ".join("%.3f" % x for x in a[:, 2]))
+    med = np.median(a[:, 1])
+    print("   shade median %.3f ms -> %.1f G tests/s, %.2f Grays/s shadow" %
+          (med, st.shadow_tests / med / 1e6, st.shadow_rays / med / 1e6))
+    sc.close()
