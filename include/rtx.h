@@ -158,6 +158,9 @@ typedef struct rtx_stats {
                                n_lights * sum over hits of the leaf's size */
     uint64_t lit_samples;   /* shadow rays that reached the light, i.e. shade()
                                evaluations (raytracing.h:45-48) */
+    uint64_t shadow_tests_run; /* of shadow_tests, those the GPU actually executed;
+                               the rest were ruled out per record by a conservative
+                               geometric screen and cannot affect a result */
     float kernel_ms[4];     /* trace, shadow+shade, merge, total on the stream
                                (only with RTX_FLAG_TIMING) */
 } rtx_stats;

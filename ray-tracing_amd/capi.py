@@ -62,7 +62,8 @@ class Hit(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("hits", C.c_uint64),
                 ("shadow_rays", C.c_uint64), ("shadow_tests", C.c_uint64),
-                ("lit_samples", C.c_uint64), ("kernel_ms", C.c_float * 4)]
+                ("lit_samples", C.c_uint64), ("shadow_tests_run", C.c_uint64),
+                ("kernel_ms", C.c_float * 4)]
 
 
 assert C.sizeof(Material) == 32 and C.sizeof(Prim) == 48 and C.sizeof(Node) == 32

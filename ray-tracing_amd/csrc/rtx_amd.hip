@@ -191,13 +191,121 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
 // float additions of normal * acne (raytracing.h:40): that chain is inherently
 // serial, so lanes 0..2 (x, y, z) run it 64 steps at a time into LDS and every
 // lane then picks up its own origin.
+//
+// Candidate list.  The reference tests every primitive of the leaf for every
+// shadow ray (intersect.h:99-117).  All shadow rays of one record start within
+// n_lights * acne of the hit point and aim at the light rectangle
+// [250, 750]^2 x {z_light} (raytracing.h:38-39), so they stay inside the pyramid
+// spanned by the start points and that rectangle (continued beyond it: there is
+// no far limit).  A triangle that lies outside one face of that pyramid, by a
+// margin far above any rounding, fails the exact test for every one of those
+// rays, so leaving it out cannot change a result.  The faces are the planes
+// through a start point and one edge of the rectangle; g(o, v) = det[v - o,
+// La - o, Lb - o] is affine in o and in v, so "all three vertices outside for
+// the first and the last start point" implies "the whole triangle outside for
+// every start point".  Once per record, lanes run that test over the leaf's
+// triangles (one each) and compact the survivors, in order, into LDS; the
+// sample loop then walks only those.  Leaves too large for the list are
+// screened in segments, once per pass.
+#define CAND_MAX 512
+#define CULL_MARGIN 0.5f // world units; start points drift by < 0.1 through rounding
+
+struct ShadeLds {
+    float chain[64 * 3];
+    float4 plane[8];
+    uint16_t cand[CAND_MAX];
+};
+
+// Lanes 0..7 each set up one pyramid face: edge (lane & 3) of the light rectangle
+// seen from the first (lane < 4) or last start point, as unit normal (pointing
+// inwards) and offset.  A degenerate face becomes all zeros, which culls nothing.
+__device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_first, f3 o_last, float zl) {
+    if (lane < 8) {
+        const f3 o = (lane < 4) ? o_first : o_last;
+        const uint32_t e = lane & 3;
+        const float xa = (e == 0 || e == 3) ? 250.f : 750.f, ya = (e < 2) ? 250.f : 750.f;
+        const float xb = (e < 2) ? 750.f : 250.f, yb = (e == 1 || e == 2) ? 750.f : 250.f;
+        // corners in order (250,250) (750,250) (750,750) (250,750); edge e = corner e -> e + 1
+        const f3 da = f3_make(xa - o.x, ya - o.y, zl - o.z);
+        const f3 db = f3_make((e == 0 || e == 1) ? 750.f - o.x : 250.f - o.x,
+                              (e == 1 || e == 2) ? 750.f - o.y : 250.f - o.y, zl - o.z);
+        (void)xb;
+        (void)yb;
+        f3 m = f3_cross(da, db);
+        const f3 dc = f3_make(500.f - o.x, 500.f - o.y, zl - o.z);
+        if (f3_dot(m, dc) < 0.f) m = f3_scale(m, -1.f);
+        const float len = __builtin_sqrtf(f3_dot(m, m));
+        float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (len > 1e-6f && len < 1e30f) {
+            m = f3_scale(m, 1.f / len);
+            pl = make_float4(m.x, m.y, m.z, f3_dot(m, o));
+        }
+        L.plane[lane] = pl;
+    }
+}
+
+// True if triangle (v0, v0 + e1, v0 + e2) may be hit by a shadow ray of the record.
+__device__ __forceinline__ bool may_be_hit(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi) {
+    const f3 v1 = f3_add(v0, e1), v2 = f3_add(v0, e2);
+    bool out = false;
+#pragma unroll 1
+    for (int e = 0; e < 4; e++) {
+        // outside face e as seen from the first AND from the last start point
+        bool both = true;
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const float4 pl = L.plane[e + 4 * w];
+            const float d0 = pl.x * v0.x + pl.y * v0.y + pl.z * v0.z - pl.w;
+            const float d1 = pl.x * v1.x + pl.y * v1.y + pl.z * v1.z - pl.w;
+            const float d2 = pl.x * v2.x + pl.y * v2.y + pl.z * v2.z - pl.w;
+            both &= (d0 < -CULL_MARGIN) & (d1 < -CULL_MARGIN) & (d2 < -CULL_MARGIN);
+        }
+        out |= both;
+    }
+    // all rays move towards the light plane in z
+    out |= (v0.z < z_lo) & (v1.z < z_lo) & (v2.z < z_lo);
+    out |= (v0.z > z_hi) & (v1.z > z_hi) & (v2.z > z_hi);
+    return !out;
+}
+
+// Screens primitives [seg, seg + n) of the leaf (n <= CAND_MAX) and writes the
+// survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.
+__device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
+                                                      uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
+                                                      float z_hi) {
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t t = base + lane;
+        bool keep = false;
+        if (t < n) {
+            const DPrim *p = leaf_prims + seg + t;
+            keep = true;
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) keep = may_be_hit(L, p->a, p->b, p->c, z_lo, z_hi);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            L.cand[pos] = (uint16_t)t;
+        }
+        total += (uint32_t)__popcll(mask);
+    }
+    return total;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
     const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
     DCounters *__restrict__ ctr) {
-    __shared__ float chain[SHADE_WAVES][64 * 3];
+    __shared__ ShadeLds lds[SHADE_WAVES];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *P = chain[wave];
+    ShadeLds &L = lds[wave];
     const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
     const float nl = (float)fr.n_lights;
 
@@ -206,6 +314,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     // an L2) and moves on to the next one when its queue is drained; queues only ever
     // drain, so after eight empty answers every wave is done.
     uint32_t q = blockIdx.x & 7, empty = 0, lit_total = 0;
+    unsigned long long tests_total = 0;
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = atomicAdd(&ctr->head[q].next, 1u);
@@ -218,16 +327,30 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         }
 
         const DRec rc = recs[ridx];
-        const uint32_t pixel = rc.pixel, leaf = rc.leaf, first = rc.first, count = rc.count;
+        const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
+        const DPrim *__restrict__ leaf_prims = prims + rc.first;
         const DMat mat = mats[rc.mat];
         const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
+        const f3 p0 = f3_make(rc.px, rc.py, rc.pz);
         f3 o, d;
         primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
-        const f3 view = f3_scale(d, -1.f);       // raytracing.h:47
-        const f3 step = f3_scale(nrm, fr.acne);  // raytracing.h:40
+        const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
+        const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
         // lanes 0..2: running origin component and its increment
-        float run = lane == 0 ? rc.px : lane == 1 ? rc.py : rc.pz;
+        float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
+
+        // pyramid of the record's shadow rays
+        const f3 o_last = f3_add(p0, f3_scale(step, nl + 1.f));
+        const float zl = fr.light_pos.z;
+        const float o_zmin = fminf(p0.z, o_last.z), o_zmax = fmaxf(p0.z, o_last.z);
+        const float z_lo = (zl > o_zmax) ? o_zmin - CULL_MARGIN : -3.0e38f;
+        const float z_hi = (zl < o_zmin) ? o_zmax + CULL_MARGIN : 3.0e38f;
+        setup_planes(L, lane, p0, o_last, zl);
+        wave_lds_sync();
+        // a leaf that fits the list is screened once, on the first pass
+        const bool one_segment = count <= CAND_MAX;
+        uint32_t n_cand = 0;
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
@@ -236,44 +359,57 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
 #pragma unroll
                 for (int s = 0; s < 64; s++) {
                     run = run + inc;
-                    P[s * 3 + lane] = run;
+                    L.chain[s * 3 + lane] = run;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t k = base + lane;
-            if (k < fr.n_lights) {
-                const f3 p = f3_make(P[lane * 3 + 0], P[lane * 3 + 1], P[lane * 3 + 2]);
-                f3 lpos = fr.light_pos;
-                light_sample(fr.seed, pixel, leaf, k, lpos.x, lpos.y);
-                const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
-                // nearest hit of the shadow ray inside the leaf (raytracing.h:45)
-                float tmin = 0.f;
-                bool any = false;
-                for (uint32_t q = 0; q < count; q++) {
-                    const DPrim *pr = prims + first + q;
-                    float t;
-                    bool ok;
-                    if ((pr->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                        ok = tri_hit(p, sd, pr->a, pr->b, pr->c, t);
-                    else
-                        ok = sph_hit(p, sd, pr->a, pr->b.y, t);
-                    if (ok && (!any || t < tmin)) {
-                        tmin = t;
-                        any = true;
+            wave_lds_sync();
+            const uint32_t ks = base + lane;
+            const bool live = ks < fr.n_lights;
+            const f3 p = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
+            f3 lpos = fr.light_pos;
+            light_sample(fr.seed, pixel, leaf, ks, lpos.x, lpos.y);
+            const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
+            // nearest hit of the shadow ray inside the leaf (raytracing.h:45)
+            float tmin = 0.f;
+            bool any = false;
+            for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
+                if (!one_segment || base == 0) {
+                    wave_lds_sync();
+                    n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
+                                              z_lo, z_hi);
+                    wave_lds_sync();
+                }
+                if (n_cand == 0) continue;
+                tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, 64u);
+                // walk the list with the next primitive's scalar loads in flight
+                uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)L.cand[0]);
+                DPrim cur = leaf_prims[seg + ci];
+                for (uint32_t c = 0; c < n_cand; c++) {
+                    const uint32_t cn = __builtin_amdgcn_readfirstlane(
+                        (uint32_t)L.cand[(c + 1 < n_cand) ? c + 1 : c]);
+                    const DPrim nxt = leaf_prims[seg + cn];
+                    if (live) {
+                        float t;
+                        bool ok;
+                        if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                            ok = tri_hit(p, sd, cur.a, cur.b, cur.c, t);
+                        else
+                            ok = sph_hit(p, sd, cur.a, cur.b.y, t);
+                        if (ok && (!any || t < tmin)) {
+                            tmin = t;
+                            any = true;
+                        }
                     }
-                }
-                // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
-                if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
-                    const f3 c = shade(nrm, view, sd, fr.light_color, mat);
-                    acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
-                    lit++;
+                    cur = nxt;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
+            if (live && (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin))))) {
+                const f3 c = shade(nrm, view, sd, fr.light_color, mat);
+                acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
+                lit++;
+            }
+            wave_lds_sync();
         }
         // sum over the lanes (fixed butterfly order, so a frame is reproducible)
 #pragma unroll
@@ -287,6 +423,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         lit_total += lit;
     }
     if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
+    if (lane == 0 && tests_total) atomicAdd(&ctr->tests_run, tests_total);
 }
 
 // ---- merge -----------------------------------------------------------------------
@@ -744,6 +881,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         stats->shadow_rays = (uint64_t)s->h_ctr->n_recs * p->n_lights;
         stats->shadow_tests = (uint64_t)s->h_ctr->leaf_prims * p->n_lights;
         stats->lit_samples = s->h_ctr->lit;
+        stats->shadow_tests_run = s->h_ctr->tests_run;
         if (timing) {
             for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
             HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[3], s->ev[0], s->ev[3]));

@@ -102,7 +102,8 @@ struct DCounters {
     uint32_t pad0;
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
     unsigned long long lit;        // light samples that were not occluded
-    uint32_t pad1[26];
+    unsigned long long tests_run;  // shadow-ray primitive tests executed
+    uint32_t pad1[24];
     // Work queue of the shading kernel, sharded eight ways so that the returning
     // atomic on one word (about 90 M/s chip-wide) does not pace the kernel: record i
     // belongs to shard i & 7; each head sits on a 128-byte line of its own.

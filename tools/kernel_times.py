@@ -38,6 +38,7 @@ for name in names or ["bunny", "buddha"]:
     print("   shade ms ", " ".join("%.3f" % x for x in a[:, 1]))
     print("   merge ms ", " ".join("%.3f" % x for x in a[:, 2]))
     med = np.median(a[:, 1])
-    print("   shade median %.3f ms -> %.1f G tests/s, %.2f Grays/s shadow" %
-          (med, st.shadow_tests / med / 1e6, st.shadow_rays / med / 1e6))
+    print("   shade median %.3f ms -> %.1f G tests/s (%.1f G run/s, %.1f %% of tests run), %.2f Grays/s shadow" %
+          (med, st.shadow_tests / med / 1e6, st.shadow_tests_run / med / 1e6,
+           100.0 * st.shadow_tests_run / max(st.shadow_tests, 1), st.shadow_rays / med / 1e6))
     sc.close()
