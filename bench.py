@@ -50,6 +50,16 @@ PEAK_FP32_UNFUSED_TFLOPS = 78.6   # the same issue rate without FMA contraction
 PEAK_HBM_GBS = 8000.0
 
 
+def hbm_traffic(workload):
+    """HBM bytes of one shade_kernel launch as measured with rocprofv3 PMC passes (a
+    separate run; see profiles/hbm_traffic.json), or None when not measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            return json.load(f)["shade_kernel"].get(workload)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_scene(rtx, scenes, name):
     """Scene description through the product's host layer (C++), not the oracle."""
     host = importlib.import_module("ray-tracing_amd.host_py")
@@ -123,20 +133,14 @@ def main():
     p.flags |= rtx.capi.RTX_FLAG_TIMING
     if world > 1:
         p.stripe_rows, p.n_parts, p.part = STRIPE_ROWS, world, rank
-    rows = rtx.part_rows(p)
-    max_rows = rows
-    if world > 1:
-        q = rtx.default_params(w, h, nl, 1)
-        q.stripe_rows, q.n_parts, q.part = STRIPE_ROWS, world, 0
-        max_rows = rtx.part_rows(q)               # part 0 has the most rows
-    tile = torch.zeros((max_rows, w, 3), dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    tiles = importlib.import_module("ray-tracing_amd.tiles")
+    gather = tiles.FrameGather(torch, dist, h, w, STRIPE_ROWS, world, rank, dev)
+    tile = gather.tile
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         st = scene.render_device(p, tile.data_ptr(), stream)
-        if world > 1:
-            dist.gather(tile, gathered, dst=0)
+        gather.run()      # RCCL gather to rank 0 + scatter of the stripes into the frame
         return st
 
     def fence():
@@ -158,13 +162,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     counts = torch.tensor([elapsed, float(st.primary_rays), float(st.shadow_rays), float(st.shadow_tests),
-                           float(st.hits), float(st.lit_samples)], dtype=torch.float64, device=dev)
+                           float(st.hits), float(st.lit_samples), float(st.shadow_tests_run)],
+                          dtype=torch.float64, device=dev)
     if world > 1:
         mx = counts.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         counts[0] = mx[0]
-    elapsed, primary, shadow, tests, hits, lit = [float(x) for x in counts.tolist()]
+    elapsed, primary, shadow, tests, hits, lit, tests_run = [float(x) for x in counts.tolist()]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -175,6 +180,8 @@ def main():
         flop = (st.shadow_tests * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
                 st.lit_samples * FLOP_PER_SHADED_SAMPLE)
         achieved = flop / (shade_avg_ms * 1e-3) / 1e12 if shade_avg_ms > 0 else 0.0
+        flop_run = (st.shadow_tests_run * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
+                    st.lit_samples * FLOP_PER_SHADED_SAMPLE)
         alg_bytes = st.shadow_tests * BYTES_PER_PRIM_TEST
         out = {
             "metric": "Mrays/s (primary+shadow)",
@@ -196,9 +203,15 @@ def main():
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                 "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
                 "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
-                "traffic": None,
+                "traffic": hbm_traffic(args.workload),
                 "launch_ms": shade_avg_ms,
                 "algorithmic_flop_per_launch": flop,
+                "executed_flop_per_launch": flop_run,
+                "executed_tflops": flop_run / (shade_avg_ms * 1e-3) / 1e12 if shade_avg_ms > 0 else 0.0,
+                "tests_run_fraction": st.shadow_tests_run / max(st.shadow_tests, 1),
+                "note": "achieved = work the reference's algorithm does for these rays (every leaf primitive "
+                        "tested for every shadow ray) / kernel time; the kernel rules out part of those tests "
+                        "per record with a conservative geometric screen (executed_* = what it really ran)",
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (shade_avg_ms * 1e-3) / 1e9 if shade_avg_ms > 0 else 0.0,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": (alg_bytes / (shade_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if shade_avg_ms > 0 else 0.0,

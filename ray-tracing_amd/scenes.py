@@ -124,8 +124,8 @@ def assemble(builder, config, mesh_dir=None):
         return mat_index[name]
 
     light = capi.Light()
-    light.position[:] = LIGHT["position"]
-    light.color[:] = LIGHT["color"]
+    light.position[:] = cfg.get("light", LIGHT)["position"]
+    light.color[:] = cfg.get("light", LIGHT)["color"]
     builder.set_light(light)
     for kind, what, where in cfg["boxes"]:
         if kind == "spheres":

@@ -104,6 +104,27 @@ def test_other_box_depths_and_seeds(op, capi, built):
         check_rgb(rgb_g, rgb_c)
 
 
+@pytest.mark.parametrize("light_z,acne,nl", [(800.0, 0.5, 100), (100.0, 0.01, 40), (520.0, 0.05, 70),
+                                             (800.0, -0.02, 30), (2000.0, 0.01, 65)])
+def test_light_heights_and_origin_drift(op, capi, scenes, rtx, light_z, acne, nl):
+    """The screening of leaf triangles against the pyramid of a record's shadow rays
+    must never drop a triangle a ray can hit: lights above, below and inside the
+    objects' z range, large and negative acne (the start points drift by
+    n_lights * acne along the normal, raytracing.h:40)."""
+    cfg = dict(scenes.CONFIGS["default"])
+    cfg["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
+    b = op.OracleBuilder(8)
+    d = scenes.assemble(b, cfg)
+    sc = rtx.Scene(d)
+    p = capi.default_params(400, 400, nl, 3)
+    p.acne = acne
+    rgb_g, hits_g = sc.render_hits(p)
+    rgb_c, _, hits_c, _ = op.render(d, p)
+    check_hits(hits_g, hits_c)
+    check_rgb(rgb_g, rgb_c)
+    sc.close()
+
+
 def test_edge_shapes(op, capi, built):
     """Tiny and ragged frames, zero samples, a frame that misses everything."""
     _, d, sc = built("default")

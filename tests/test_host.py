@@ -121,3 +121,20 @@ def test_png_writer(host, tmp_path):
     raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 3)
     assert (raw[:, 0] == 0).all()
     assert np.array_equal(raw[:, 1:].reshape(37, 53, 3), rgb[::-1])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/main.cpp"), reason="reference tree not present")
+def test_reference_main_builds_against_the_drop_in(tmp_path):
+    """The reference's main.cpp with its one include line switched to the drop-in header
+    (the edit INTEGRATION.md describes) compiles as C++11 and links against the two
+    libraries; nothing else in it changes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open("/root/reference/main.cpp").read()
+    assert text.count('#include "raytracing.h"') == 1
+    (tmp_path / "main_dropin.cpp").write_text(text.replace('#include "raytracing.h"', '#include "rtx_dropin.hpp"'))
+    cmd = ["g++", "-std=c++11", "-I", os.path.join(root, "include"), str(tmp_path / "main_dropin.cpp"),
+           "-o", str(tmp_path / "main"),
+           "-L", os.path.join(root, "ray-tracing_amd", "host"), "-lrtx_host",
+           "-L", os.path.join(root, "ray-tracing_amd", "csrc"), "-lrtx_amd"]
+    subprocess.check_call(cmd)
