@@ -87,5 +87,5 @@ def part_rows(p):
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librtx_amd.so")
+LIB_PATH = os.environ.get("RTX_AMD_LIB") or os.path.join(_HERE, "csrc", "librtx_amd.so")
 HOST_LIB_PATH = os.path.join(_HERE, "host", "librtx_host.so")

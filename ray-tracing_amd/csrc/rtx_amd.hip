@@ -210,8 +210,10 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
 #define CAND_MAX 512
 #define CULL_MARGIN 0.5f // world units; start points drift by < 0.1 through rounding
 
+#define PASS_SAMPLES 128 // light samples per pass: two per lane
+
 struct ShadeLds {
-    float chain[64 * 3];
+    float chain[PASS_SAMPLES * 3];
     float4 plane[8];
     uint16_t cand[CAND_MAX];
 };
@@ -354,24 +356,49 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
-        for (uint32_t base = 0; base < fr.n_lights; base += 64) {
+        // Each pass takes 128 samples: lane l owns samples base + l and base + 64 + l and
+        // carries both rays through the triangle tests as packed pairs.
+        for (uint32_t base = 0; base < fr.n_lights; base += PASS_SAMPLES) {
+            const bool second = base + 64 < fr.n_lights; // wave-uniform: any sample in the upper half?
             if (lane < 3) {
 #pragma unroll
                 for (int s = 0; s < 64; s++) {
                     run = run + inc;
                     L.chain[s * 3 + lane] = run;
                 }
+                if (second) {
+#pragma unroll
+                    for (int s = 64; s < PASS_SAMPLES; s++) {
+                        run = run + inc;
+                        L.chain[s * 3 + lane] = run;
+                    }
+                }
             }
             wave_lds_sync();
-            const uint32_t ks = base + lane;
-            const bool live = ks < fr.n_lights;
-            const f3 p = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
-            f3 lpos = fr.light_pos;
-            light_sample(fr.seed, pixel, leaf, ks, lpos.x, lpos.y);
-            const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
-            // nearest hit of the shadow ray inside the leaf (raytracing.h:45)
-            float tmin = 0.f;
-            bool any = false;
+            const uint32_t k1 = base + lane, k2 = k1 + 64;
+            const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
+            const f3 p1 = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
+            f3 p2 = p1;
+            f3 l1 = fr.light_pos, l2 = fr.light_pos;
+            light_sample(fr.seed, pixel, leaf, k1, l1.x, l1.y);
+            const f3 sd1 = f3_normalize(f3_sub(l1, p1)); // raytracing.h:43
+            f3 sd2 = sd1;
+            if (second) {
+                p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
+                             L.chain[(64 + lane) * 3 + 2]);
+                light_sample(fr.seed, pixel, leaf, k2, l2.x, l2.y);
+                sd2 = f3_normalize(f3_sub(l2, p2));
+            }
+            ray2 rr;
+            rr.ox = (v2f){p1.x, p2.x};
+            rr.oy = (v2f){p1.y, p2.y};
+            rr.oz = (v2f){p1.z, p2.z};
+            rr.dx = (v2f){sd1.x, sd2.x};
+            rr.dy = (v2f){sd1.y, sd2.y};
+            rr.dz = (v2f){sd1.z, sd2.z};
+            // nearest hit of each shadow ray inside the leaf (raytracing.h:45)
+            float tmin1 = 0.f, tmin2 = 0.f;
+            bool any1 = false, any2 = false;
             for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
                     wave_lds_sync();
                 }
                 if (n_cand == 0) continue;
-                tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, 64u);
+                tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, (uint32_t)PASS_SAMPLES);
                 // walk the list with the next primitive's scalar loads in flight
                 uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)L.cand[0]);
                 DPrim cur = leaf_prims[seg + ci];
@@ -388,25 +415,37 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
                     const uint32_t cn = __builtin_amdgcn_readfirstlane(
                         (uint32_t)L.cand[(c + 1 < n_cand) ? c + 1 : c]);
                     const DPrim nxt = leaf_prims[seg + cn];
-                    if (live) {
-                        float t;
-                        bool ok;
-                        if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                            ok = tri_hit(p, sd, cur.a, cur.b, cur.c, t);
-                        else
-                            ok = sph_hit(p, sd, cur.a, cur.b.y, t);
-                        if (ok && (!any || t < tmin)) {
-                            tmin = t;
-                            any = true;
-                        }
+                    bool ok1 = live1, ok2 = live2;
+                    v2f t = (v2f){0.f, 0.f};
+                    if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                        tri_hit2(rr, cur.a, cur.b, cur.c, ok1, ok2, t);
+                    } else {
+                        float ta = 0.f, tb = 0.f;
+                        ok1 = ok1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
+                        ok2 = ok2 && sph_hit(p2, sd2, cur.a, cur.b.y, tb);
+                        t = (v2f){ta, tb};
+                    }
+                    if (ok1 && (!any1 || t.x < tmin1)) {
+                        tmin1 = t.x;
+                        any1 = true;
+                    }
+                    if (ok2 && (!any2 || t.y < tmin2)) {
+                        tmin2 = t.y;
+                        any2 = true;
                     }
                     cur = nxt;
                 }
             }
-            // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
-            if (live && (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin))))) {
-                const f3 c = shade(nrm, view, sd, fr.light_color, mat);
+            // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
+            // samples of a lane are added in sample order
+            if (live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))))) {
+                const f3 c = shade(nrm, view, sd1, fr.light_color, mat);
                 acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
+                lit++;
+            }
+            if (live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))))) {
+                const f3 c = shade(nrm, view, sd2, fr.light_color, mat);
+                acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f));
                 lit++;
             }
             wave_lds_sync();

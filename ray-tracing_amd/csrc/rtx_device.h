@@ -158,6 +158,45 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &
     return t > eps;
 }
 
+// Two rays per lane against one triangle.  Every operation is the same IEEE binary32
+// operation as in tri_hit, done on a pair of values at once so that it maps to the
+// packed v_pk_mul_f32 / v_pk_add_f32 instructions (one issue slot for two results);
+// no operation is fused or reordered.  ok1 / ok2: on entry whether the ray takes
+// part, on return whether it hits (then t holds the distance).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct ray2 {
+    v2f ox, oy, oz; // origins
+    v2f dx, dy, dz; // unit directions
+};
+
+__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool &ok1, bool &ok2, v2f &t) {
+    const float eps = 0.0000001f;
+    const v2f hx = r.dy * e2.z - r.dz * e2.y;
+    const v2f hy = r.dz * e2.x - r.dx * e2.z;
+    const v2f hz = r.dx * e2.y - r.dy * e2.x;
+    const v2f a = e1.x * hx + e1.y * hy + e1.z * hz;
+    ok1 = ok1 && !(a.x > -eps && a.x < eps);
+    ok2 = ok2 && !(a.y > -eps && a.y < eps);
+    if (!(ok1 || ok2)) return;
+    const v2f f = 1.f / a;
+    const v2f sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
+    const v2f u = f * (sx * hx + sy * hy + sz * hz);
+    ok1 = ok1 && !(u.x < 0.f || u.x > 1.f);
+    ok2 = ok2 && !(u.y < 0.f || u.y > 1.f);
+    if (!(ok1 || ok2)) return;
+    const v2f qx = sy * e1.z - sz * e1.y;
+    const v2f qy = sz * e1.x - sx * e1.z;
+    const v2f qz = sx * e1.y - sy * e1.x;
+    const v2f v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+    const v2f uv = u + v;
+    ok1 = ok1 && !(v.x < 0.f || uv.x > 1.f);
+    ok2 = ok2 && !(v.y < 0.f || uv.y > 1.f);
+    t = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    ok1 = ok1 && t.x > eps;
+    ok2 = ok2 && t.y > eps;
+}
+
 // intersect.h:1-18 (distance only)
 __device__ __forceinline__ bool sph_hit(f3 o, f3 d, f3 c, float r2, float &t) {
     f3 pos = f3_sub(o, c);
