@@ -173,6 +173,12 @@ int rtx_device_count(void);
 /* Message for the calling thread's last failed call ("" if none). */
 const char *rtx_last_error(void);
 
+/* Device self-test with no counterpart in the reference: checks, for every binary32
+ * value in its working range, that the packed reciprocal used inside the ray-triangle
+ * test returns the bits of the correctly rounded IEEE quotient 1.f / a (the reference's
+ * `f = 1.f / a`, intersect.h:41).  *checked = values compared, *mismatches must be 0. */
+rtx_status rtx_selftest(int device, uint64_t *checked, uint64_t *mismatches);
+
 void rtx_params_default(rtx_params *p);
 /* Rows / pixels a call with these parameters renders (row tiling applied). */
 uint32_t rtx_part_rows(const rtx_params *p);

@@ -38,6 +38,7 @@ def lib():
         L.rtx_params_default.argtypes = [C.POINTER(Params)]
         L.rtx_part_rows.restype = C.c_uint32
         L.rtx_part_rows.argtypes = [C.POINTER(Params)]
+        L.rtx_selftest.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.rtx_scene_destroy.argtypes = [C.c_void_p]
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
@@ -56,6 +57,13 @@ def _check(status):
 
 def device_count():
     return lib().rtx_device_count()
+
+
+def selftest(device=0):
+    """(values checked, mismatches) of the packed exact reciprocal against 1.f / a."""
+    n, bad = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().rtx_selftest(device, C.byref(n), C.byref(bad)))
+    return int(n.value), int(bad.value)
 
 
 class Scene:

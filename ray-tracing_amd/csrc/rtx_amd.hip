@@ -545,6 +545,31 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_kernel(
     out[2] = clamp_color(rz);
 }
 
+// ---- self test ------------------------------------------------------------------
+// rcp2_exact against the plain division for every binary32 value in its range.
+__global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long *checked) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t nb = 0, nc = 0;
+    // 2^32 bit patterns, two per iteration
+    for (unsigned long long i = (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 2; i < (1ull << 32);
+         i += (unsigned long long)stride * 2) {
+        const float x = __uint_as_float((uint32_t)i), y = __uint_as_float((uint32_t)i + 1u);
+        const v2f r = rcp2_exact((v2f){x, y});
+        const bool inx = __builtin_fabsf(x) >= RCP2_MIN && __builtin_fabsf(x) < RCP2_MAX;
+        const bool iny = __builtin_fabsf(y) >= RCP2_MIN && __builtin_fabsf(y) < RCP2_MAX;
+        if (inx) {
+            nc++;
+            nb += __float_as_uint(r.x) != __float_as_uint(1.f / x);
+        }
+        if (iny) {
+            nc++;
+            nb += __float_as_uint(r.y) != __float_as_uint(1.f / y);
+        }
+    }
+    if (nb) atomicAdd(bad, (unsigned long long)nb);
+    atomicAdd(checked, (unsigned long long)nc);
+}
+
 // ===========================================================================
 // Host side: scene upload and the C ABI
 // ===========================================================================
@@ -595,6 +620,26 @@ extern "C" int rtx_device_count(void) {
 }
 
 extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
+
+extern "C" rtx_status rtx_selftest(int device, uint64_t *checked, uint64_t *mismatches) {
+    if (!checked || !mismatches) return fail(RTX_ERR_INVALID, "null argument");
+    if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 16));
+    hipError_t e = hipMemset(d, 0, 16);
+    if (e == hipSuccess) {
+        selftest_rcp_kernel<<<4096, 256>>>(d, d + 1);
+        e = hipGetLastError();
+    }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
+    *mismatches = h[0];
+    *checked = h[1];
+    return RTX_OK;
+}
 
 extern "C" void rtx_params_default(rtx_params *p) {
     if (!p) return;

@@ -170,6 +170,24 @@ struct ray2 {
     v2f dx, dy, dz; // unit directions
 };
 
+// 1 / a for two values at once, bit-identical to the correctly rounded IEEE quotient
+// 1.f / a for RCP2_MIN <= |a| < RCP2_MAX: the same v_rcp_f32 seed and the same six
+// fused multiply-adds that the compiler's division expansion performs when no
+// operand scaling is needed, issued as packed v_pk_fma_f32.  Verified exhaustively
+// over that range by rtx_selftest().  Outside the range use the plain division.
+#define RCP2_MIN 5.0e-8f
+#define RCP2_MAX 1.0e18f
+__device__ __forceinline__ v2f rcp2_exact(v2f a) {
+    const v2f one = (v2f){1.f, 1.f};
+    const v2f r0 = (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+    const v2f e0 = __builtin_elementwise_fma(-a, r0, one);
+    const v2f r1 = __builtin_elementwise_fma(e0, r0, r0);
+    const v2f e1 = __builtin_elementwise_fma(-a, r1, one);
+    const v2f r2 = __builtin_elementwise_fma(e1, r1, r1);
+    const v2f e2 = __builtin_elementwise_fma(-a, r2, one);
+    return __builtin_elementwise_fma(e2, r1, r2);
+}
+
 __device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool &ok1, bool &ok2, v2f &t) {
     const float eps = 0.0000001f;
     const v2f hx = r.dy * e2.z - r.dz * e2.y;
@@ -179,7 +197,13 @@ __device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, boo
     ok1 = ok1 && !(a.x > -eps && a.x < eps);
     ok2 = ok2 && !(a.y > -eps && a.y < eps);
     if (!(ok1 || ok2)) return;
-    const v2f f = 1.f / a;
+    // |a| >= 1e-7 for every ray still taking part; only the upper end needs a check
+    const bool wide = (ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX));
+    v2f f;
+    if (__builtin_expect(__any(wide), 0))
+        f = 1.f / a;
+    else
+        f = rcp2_exact(a);
     const v2f sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
     const v2f u = f * (sx * hx + sy * hy + sz * hz);
     ok1 = ok1 && !(u.x < 0.f || u.x > 1.f);

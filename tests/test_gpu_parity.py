@@ -188,6 +188,13 @@ def test_record_buffer_growth(op, capi, rtx, scenes):
     sc.close()
 
 
+def test_packed_reciprocal_is_the_ieee_quotient(rtx):
+    """intersect.h:41 `f = 1.f / a`: the kernel's packed reciprocal must return the bits
+    of the correctly rounded quotient for every float it is used for (exhaustive)."""
+    checked, bad = rtx.selftest(0)
+    assert checked > 1.4e9 and bad == 0
+
+
 def test_limits_are_errors(capi, rtx, built):
     _, d, sc = built("spheres")
     p = capi.default_params(16, 16, 70000, 1)
