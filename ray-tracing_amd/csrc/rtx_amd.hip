@@ -72,18 +72,32 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
         const uint32_t first = nd.link, count = nd.info >> 16, leaf = nd.info & 0xFFFFu;
         float best_t = 0.f;
         uint32_t best = RTXD_NONE;
-        for (uint32_t k = 0; k < count; k++) {
-            const DPrim *p = prims + first + k;
-            const f3 a = p->a, b = p->b;
-            float t;
-            bool ok;
-            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                ok = tri_hit(o, d, a, b, p->c, t);
-            else
-                ok = sph_hit(o, d, a, b.y, t);
-            if (ok && (best == RTXD_NONE || t < best_t)) {
-                best_t = t;
-                best = k;
+#ifdef ABLATE_LEAF
+        if (count > 100000)
+#endif
+        {
+            // the next primitive's loads are issued before the current one is tested
+            const DPrim *p = prims + first;
+            f3 a = p->a, b = p->b, c = p->c;
+            uint32_t tm = p->type_mat;
+            for (uint32_t k = 0; k < count; k++) {
+                const DPrim *pn = prims + first + ((k + 1 < count) ? k + 1 : k);
+                const f3 na = pn->a, nb = pn->b, nc = pn->c;
+                const uint32_t ntm = pn->type_mat;
+                float t;
+                bool ok;
+                if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                    ok = tri_hit(o, d, a, b, c, t);
+                else
+                    ok = sph_hit(o, d, a, b.y, t);
+                if (ok && (best == RTXD_NONE || t < best_t)) {
+                    best_t = t;
+                    best = k;
+                }
+                a = na;
+                b = nb;
+                c = nc;
+                tm = ntm;
             }
         }
         if (best != RTXD_NONE) {
