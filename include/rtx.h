@@ -104,7 +104,8 @@ typedef struct rtx_scene_desc {
 
 /* Limits (checked, RTX_ERR_LIMIT when exceeded). */
 #define RTX_MAX_LEAVES 65535u  /* leaf index is 16 bits of the sampler counter */
-#define RTX_MAX_LIGHTS 65535u  /* sample index is the other 16 bits */
+#define RTX_MAX_LIGHTS 65535u  /* sample index is the other 16 bits:
+                                  n_lights * (max_depth + 1) must not exceed it */
 #define RTX_MAX_MATERIALS 256u
 
 /*
@@ -115,7 +116,7 @@ typedef struct rtx_params {
     uint32_t width;     /* WIDTH  (raytracing.h:12) */
     uint32_t height;    /* HEIGHT (raytracing.h:13) */
     uint32_t n_lights;  /* NB_LIGHTS (raytracing.h:19) */
-    uint32_t max_depth; /* MAX_DEPTH (raytracing.h:18); only 0 is implemented */
+    uint32_t max_depth; /* MAX_DEPTH (raytracing.h:18): mirror bounces, 0..8 */
     uint32_t seed;      /* key of the counter-based light sampler */
     float acne;         /* raytracing.h:21 */
     float camera[3];    /* raytracing.h:112 */
@@ -153,9 +154,9 @@ typedef struct rtx_hit {
 typedef struct rtx_stats {
     uint64_t primary_rays;  /* pixels rendered by this call */
     uint64_t hits;          /* (pixel, leaf) hit records */
-    uint64_t shadow_rays;   /* hits * n_lights */
-    uint64_t shadow_tests;  /* primitive tests done for shadow rays:
-                               n_lights * sum over hits of the leaf's size */
+    uint64_t shadow_rays;   /* (hits + mirror-bounce hits) * n_lights */
+    uint64_t shadow_tests;  /* primitive tests the reference does for those rays:
+                               n_lights * sum over those hits of the leaf's size */
     uint64_t lit_samples;   /* shadow rays that reached the light, i.e. shade()
                                evaluations (raytracing.h:45-48) */
     uint64_t shadow_tests_run; /* of shadow_tests, those the GPU actually executed;

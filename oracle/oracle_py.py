@@ -22,7 +22,8 @@ REF_SO = os.path.join(_HERE, "_ref", "libref.so")
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("primary_rays", "slab_tests", "leaf_visits", "primary_prim_tests", "hits",
-                 "shadow_rays", "shadow_prim_tests", "shaded_samples", "nan_channels")]
+                 "shadow_rays", "shadow_prim_tests", "shaded_samples", "nan_channels",
+                 "bounce_rays", "bounce_prim_tests")]
 
 
 def _f3(v):

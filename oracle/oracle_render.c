@@ -269,15 +269,18 @@ static void hv_push(hitvec *h, const rtx_hit *r) {
     h->v[h->n++] = *r;
 }
 
-/* raytracing.h:29-72 for one leaf (MAX_DEPTH = 0: the reflection branch is
- * not taken).  Returns 1 and the colour when the primary ray hits something
- * in the leaf. */
+/* raytracing.h:29-72 for one leaf.  `depth` is Ray::depth: 0 for the primary ray, +1
+ * per mirror bounce (raytracing.h:51-61; the bounce is traced inside the SAME leaf box).
+ * The light sampler is indexed by depth * n_lights + k so that every bounce draws its
+ * own samples.  Returns 1 and the colour when the ray hits something in the leaf. */
 static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pixel,
-                      uint32_t leaf_id, v3 o, v3 d, v3 *color, rtx_hit *rec, orc_stats *st) {
+                      uint32_t leaf_id, v3 o, v3 d, uint32_t depth, v3 *color, rtx_hit *rec,
+                      orc_stats *st) {
     const rtx_leaf *lf = &sc->leaves[leaf_id];
     const rtx_prim *pr = sc->prims + lf->first;
     isect hit;
-    int win = nearest_in_leaf(o, d, pr, lf->count, &hit, &st->primary_prim_tests);
+    int win = nearest_in_leaf(o, d, pr, lf->count, &hit,
+                              depth ? &st->bounce_prim_tests : &st->primary_prim_tests);
     if (win < 0) return 0;
     const rtx_material *mat = &sc->materials[pr[win].material];
     v3 lc = ld3(sc->light.color);
@@ -287,7 +290,7 @@ static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pi
     float nl = (float)p->n_lights;
     for (uint32_t k = 0; k < p->n_lights; k++) {
         float xy[2];
-        orc_light_sample(p->seed, pixel, leaf_id, k, xy);
+        orc_light_sample(p->seed, pixel, leaf_id, depth * p->n_lights + k, xy);
         lpos.x = xy[0];
         lpos.y = xy[1];
         pos = v3_add(pos, v3_scale(hit.nrm, p->acne)); /* accumulates, raytracing.h:40 */
@@ -302,20 +305,35 @@ static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pi
             st->shaded_samples++;
         }
     }
-    *color = col;
-    rec->pixel = pixel;
-    rec->leaf = leaf_id;
-    rec->prim = pr[win].id;
-    rec->t = hit.t;
-    st3(rec->color, col);
+    v3 ret = col;
+    if (depth < p->max_depth) {
+        /* raytracing.h:53-60; reflect() is vec3.h:103-106: I - N * 2.f * dot(N, I) */
+        v3 n2 = v3_scale(hit.nrm, 2.f);
+        v3 rd = v3_normalize(v3_sub(d, v3_scale(n2, v3_dot(hit.nrm, d))));
+        v3 ro = v3_add(pos, v3_scale(rd, p->acne)); /* pos: after all the acne steps */
+        v3 cr = {0.f, 0.f, 0.f};
+        st->bounce_rays++;
+        trace_leaf(sc, p, pixel, leaf_id, ro, rd, depth + 1, &cr, NULL, st);
+        float fres = rdm_fresnel(v3_dot(rd, hit.nrm), 1.f, mat->ior);
+        ret = v3_add(col, v3_mul(v3_scale(ld3(mat->specular), fres), cr));
+    }
+    *color = ret;
+    if (rec) {
+        rec->pixel = pixel;
+        rec->leaf = leaf_id;
+        rec->prim = pr[win].id;
+        rec->t = hit.t;
+        st3(rec->color, ret);
+    }
     return 1;
 }
 
 int orc_render(const rtx_scene_desc *sc, const rtx_params *p, uint8_t *rgb, float *fcolor,
                rtx_hit *hits, uint64_t hit_cap, uint64_t *n_hits, orc_stats *stats, int threads) {
     if (!sc || !p || p->width == 0 || p->height == 0) return 1;
-    if (p->max_depth != 0) return 1;
-    if (p->n_lights > RTX_MAX_LIGHTS || sc->n_leaves > RTX_MAX_LEAVES) return 1;
+    if ((uint64_t)p->n_lights * ((uint64_t)p->max_depth + 1) > RTX_MAX_LIGHTS ||
+        sc->n_leaves > RTX_MAX_LEAVES)
+        return 1;
     {
         /* nesting depth of the pre-order array */
         uint32_t end[ORC_MAX_NEST];
@@ -400,7 +418,7 @@ int orc_render(const rtx_scene_desc *sc, const rtx_params *p, uint8_t *rgb, floa
                     st.leaf_visits++;
                     v3 nc;
                     rtx_hit rec;
-                    if (trace_leaf(sc, p, pixel, nd->leaf, o, d, &nc, &rec, &st)) {
+                    if (trace_leaf(sc, p, pixel, nd->leaf, o, d, 0, &nc, &rec, &st)) {
                         st.hits++;
                         rec.ordinal = ordinal++;
                         if (want_hits) hv_push(&row_hits[r], &rec);
@@ -432,6 +450,8 @@ int orc_render(const rtx_scene_desc *sc, const rtx_params *p, uint8_t *rgb, floa
             total.shadow_prim_tests += st.shadow_prim_tests;
             total.shaded_samples += st.shaded_samples;
             total.nan_channels += st.nan_channels;
+            total.bounce_rays += st.bounce_rays;
+            total.bounce_prim_tests += st.bounce_prim_tests;
         }
     }
     uint64_t nh = 0;

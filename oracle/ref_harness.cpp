@@ -151,7 +151,7 @@ struct Ctx {
 
 /* raytracing.h:29-72 around the reference's intersect_scene / shade /
  * coord_out_of_scene (MAX_DEPTH = 0). */
-bool leaf_trace(Ctx &c, Light &light, Ray &ray, Box &box, Vec3F &out) {
+bool leaf_trace(Ctx &c, Light &light, Ray &ray, Box &box, Vec3F &out, bool record = true) {
     Intersection hit;
     if (!intersect_scene(ray, box, hit)) return false;
     uint32_t leaf = c.b->leaf_index[&box];
@@ -171,7 +171,7 @@ bool leaf_trace(Ctx &c, Light &light, Ray &ray, Box &box, Vec3F &out) {
     float dist = hit.distance;
     for (uint32_t k = 0; k < c.p->n_lights; k++) {
         float xy[2];
-        light_sample(c.p->seed, c.pixel, leaf, k, xy);
+        light_sample(c.p->seed, c.pixel, leaf, (uint32_t)ray.depth * c.p->n_lights + k, xy);
         light.position.x = xy[0];
         light.position.y = xy[1];
         hit.position = hit.position + (hit.normale * c.p->acne);
@@ -188,16 +188,31 @@ bool leaf_trace(Ctx &c, Light &light, Ray &ray, Box &box, Vec3F &out) {
             c.shaded++;
         }
     }
+    /* raytracing.h:51-61 with the reference's reflect() and RDM_Fresnel() */
+    if ((uint32_t)ray.depth < c.p->max_depth) {
+        Ray bounce;
+        Vec3F dir = reflect(ray.direction, hit.normale);
+        dir = normalize(dir);
+        bounce.origin = hit.position + dir * c.p->acne;
+        bounce.direction = dir;
+        bounce.depth = ray.depth + 1;
+        Vec3F far = {0.f, 0.f, 0.f};
+        if (!leaf_trace(c, light, bounce, box, far, false)) far = Vec3F{0.f, 0.f, 0.f};
+        sum = sum + hit.object.material.specularColor *
+                        RDM_Fresnel(dot(bounce.direction, hit.normale), 1.f, hit.object.material.IOR) * far;
+    }
     out = sum;
-    rtx_hit h;
-    h.pixel = c.pixel;
-    h.ordinal = c.ordinal++;
-    h.leaf = leaf;
-    h.prim = prim;
-    h.t = dist;
-    S(h.color, sum);
-    if (c.hits) c.hits->push_back(h);
-    c.nhits++;
+    if (record) {
+        rtx_hit h;
+        h.pixel = c.pixel;
+        h.ordinal = c.ordinal++;
+        h.leaf = leaf;
+        h.prim = prim;
+        h.t = dist;
+        S(h.color, sum);
+        if (c.hits) c.hits->push_back(h);
+        c.nhits++;
+    }
     return true;
 }
 

@@ -73,6 +73,8 @@ typedef struct orc_stats {
     uint64_t shadow_prim_tests;
     uint64_t shaded_samples;     /* shade() calls */
     uint64_t nan_channels;       /* pixel channels that reached clamp_color as NaN */
+    uint64_t bounce_rays;        /* mirror rays (raytracing.h:51-61), max_depth > 0 only */
+    uint64_t bounce_prim_tests;  /* primitive tests done for them */
 } orc_stats;
 
 /* rgb: rtx_part_rows * width * 3 bytes (may be NULL).  hits: up to hit_cap

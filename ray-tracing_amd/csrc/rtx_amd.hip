@@ -226,7 +226,11 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
 
 #define PASS_SAMPLES 128 // light samples per pass: two per lane
 
+#define MAX_BOUNCES 8 // deepest mirror recursion (rtx_params::max_depth) the kernel folds
+
 struct ShadeLds {
+    float4 level_sum[MAX_BOUNCES + 2];    // per bounce level: sum of its light samples
+    float4 level_weight[MAX_BOUNCES + 1]; // specular * Fresnel of the level's hit
     float chain[PASS_SAMPLES * 3];
     float4 plane[8];
     uint16_t cand[CAND_MAX];
@@ -315,6 +319,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// BOUNCE = false is the build for max_depth = 0 (the reference as committed): the
+// mirror-bounce code and its registers are compiled out.
+template <bool BOUNCE>
 __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
     const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
@@ -329,7 +336,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     // starts on the queue of its block (blocks b and b + 8 tend to share an XCD, hence
     // an L2) and moves on to the next one when its queue is drained; queues only ever
     // drain, so after eight empty answers every wave is done.
-    uint32_t q = blockIdx.x & 7, empty = 0, lit_total = 0;
+    uint32_t q = blockIdx.x & 7, empty = 0, lit_total = 0, bounce_hits = 0;
+    unsigned long long bounce_prims = 0;
     unsigned long long tests_total = 0;
     for (;;) {
         uint32_t k = 0;
@@ -345,13 +353,18 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
         const DPrim *__restrict__ leaf_prims = prims + rc.first;
-        const DMat mat = mats[rc.mat];
-        const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
-        const f3 p0 = f3_make(rc.px, rc.py, rc.pz);
+        // state of the current hit: the primary one first, then one per mirror bounce
+        // (raytracing.h:51-61; a bounce is traced inside the same leaf)
+        DMat mat = mats[rc.mat];
+        f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
+        f3 p0 = f3_make(rc.px, rc.py, rc.pz);
         f3 o, d;
         primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+        uint32_t depth = 0;
+        for (;;) {
         const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
         const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
+        const uint32_t k_off = depth * fr.n_lights; // every bounce draws its own light samples
         // lanes 0..2: running origin component and its increment
         float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
@@ -394,13 +407,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
             const f3 p1 = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
             f3 p2 = p1;
             f3 l1 = fr.light_pos, l2 = fr.light_pos;
-            light_sample(fr.seed, pixel, leaf, k1, l1.x, l1.y);
+            light_sample(fr.seed, pixel, leaf, k_off + k1, l1.x, l1.y);
             const f3 sd1 = f3_normalize(f3_sub(l1, p1)); // raytracing.h:43
             f3 sd2 = sd1;
             if (second) {
                 p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
                              L.chain[(64 + lane) * 3 + 2]);
-                light_sample(fr.seed, pixel, leaf, k2, l2.x, l2.y);
+                light_sample(fr.seed, pixel, leaf, k_off + k2, l2.x, l2.y);
                 sd2 = f3_normalize(f3_sub(l2, p2));
             }
             ray2 rr;
@@ -472,11 +485,87 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
             acc.z += __shfl_xor(acc.z, off);
             lit += __shfl_xor(lit, off);
         }
-        if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
         lit_total += lit;
+        if (lane == 0) L.level_sum[depth] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (!BOUNCE || depth >= fr.max_depth) break;
+
+        // ---- mirror bounce (raytracing.h:53-60) ----
+        // the reflected ray starts from the hit position after all the acne steps
+        f3 pos = p0;
+        if (fr.n_lights) {
+            const uint32_t slot = (fr.n_lights - 1) % PASS_SAMPLES;
+            pos = f3_make(L.chain[slot * 3 + 0], L.chain[slot * 3 + 1], L.chain[slot * 3 + 2]);
+        }
+        const f3 n2 = f3_scale(nrm, 2.f); // reflect(), vec3.h:103-106: I - N * 2.f * dot(N, I)
+        const f3 rd = f3_normalize(f3_sub(d, f3_scale(n2, f3_dot(nrm, d))));
+        const f3 ro = f3_add(pos, f3_scale(rd, fr.acne));
+        const float fres = rdm_fresnel(f3_dot(rd, nrm), mat);
+        if (lane == 0) {
+            const f3 w = f3_scale(mat.spec, fres);
+            L.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);
+        }
+        // nearest hit of the reflected ray in the leaf: lanes over the primitives, then
+        // the smallest distance wins, the earliest primitive on ties (intersect.h:120-128)
+        float bt = 0.f;
+        uint32_t bk = RTXD_NONE;
+        for (uint32_t kk = lane; kk < count; kk += 64) {
+            const DPrim *pp = leaf_prims + kk;
+            float t;
+            bool ok;
+            if ((pp->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                ok = tri_hit(ro, rd, pp->a, pp->b, pp->c, t);
+            else
+                ok = sph_hit(ro, rd, pp->a, pp->b.y, t);
+            if (ok && (bk == RTXD_NONE || t < bt)) {
+                bt = t;
+                bk = kk;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ot = __shfl_xor(bt, off);
+            const uint32_t ok2 = __shfl_xor(bk, off);
+            if (ok2 != RTXD_NONE && (bk == RTXD_NONE || ot < bt || (ot == bt && ok2 < bk))) {
+                bt = ot;
+                bk = ok2;
+            }
+        }
+        bk = __builtin_amdgcn_readfirstlane(bk); // the same in every lane after the reduction
+        bt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bt)));
+        depth++;
+        if (bk == RTXD_NONE) { // the bounce leaves the leaf: it contributes black
+            if (lane == 0) L.level_sum[depth] = make_float4(0.f, 0.f, 0.f, 0.f);
+            break;
+        }
+        bounce_hits++;
+        bounce_prims += count;
+        const DPrim *hp = leaf_prims + bk;
+        const uint32_t htm = hp->type_mat;
+        p0 = f3_add(ro, f3_scale(rd, bt)); // intersect.h:20, :58
+        nrm = ((htm & 0xFFu) == RTX_PRIM_TRIANGLE) ? hp->n : f3_normalize(f3_sub(p0, hp->a));
+        mat = mats[htm >> 8];
+        d = rd;
+        wave_lds_sync();
+        } // bounce loop
+        // colour of the primary hit = its own samples + weight * colour of the bounce, folded
+        // from the deepest level (ret = color + specular * Fresnel * color_reflect, :60)
+        wave_lds_sync();
+        if (lane == 0) {
+            float4 c = L.level_sum[depth];
+            for (uint32_t lv = depth; lv-- > 0;) {
+                const float4 sm = L.level_sum[lv], w = L.level_weight[lv];
+                c = make_float4(sm.x + w.x * c.x, sm.y + w.y * c.y, sm.z + w.z * c.z, 0.f);
+            }
+            colors[ridx] = c;
+        }
+        wave_lds_sync();
     }
     if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
     if (lane == 0 && tests_total) atomicAdd(&ctr->tests_run, tests_total);
+    if (lane == 0 && bounce_hits) {
+        atomicAdd(&ctr->bounce_hits, (unsigned long long)bounce_hits);
+        atomicAdd(&ctr->bounce_prims, bounce_prims);
+    }
 }
 
 // ---- merge -----------------------------------------------------------------------
@@ -880,8 +969,9 @@ static rtx_status check_params(const rtx_scene *s, const rtx_params *p) {
     if (!s || !p) return fail(RTX_ERR_INVALID, "null argument");
     if (p->width == 0 || p->height == 0) return fail(RTX_ERR_INVALID, "empty frame");
     if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return fail(RTX_ERR_LIMIT, "more than 2^32 pixels");
-    if (p->n_lights > RTX_MAX_LIGHTS) return fail(RTX_ERR_LIMIT, "more than 65535 light samples");
-    if (p->max_depth != 0) return fail(RTX_ERR_INVALID, "max_depth > 0 (reflections) is not implemented");
+    if (p->max_depth > MAX_BOUNCES) return fail(RTX_ERR_LIMIT, "max_depth above 8");
+    if ((uint64_t)p->n_lights * (p->max_depth + 1ull) > RTX_MAX_LIGHTS)
+        return fail(RTX_ERR_LIMIT, "more than 65535 light samples per leaf hit (n_lights * (max_depth + 1))");
     if (p->n_parts > 1 && (p->stripe_rows == 0 || p->part >= p->n_parts))
         return fail(RTX_ERR_INVALID, "bad row tiling");
     return RTX_OK;
@@ -933,6 +1023,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     fr.stripe_rows = (p->n_parts > 1) ? p->stripe_rows : p->height;
     fr.part = (p->n_parts > 1) ? p->part : 0;
     fr.n_lights = p->n_lights;
+    fr.max_depth = p->max_depth;
     fr.seed = p->seed;
     fr.acne = p->acne;
     fr.camera = host_f3(p->camera);
@@ -958,8 +1049,12 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
                                                     s->rec_cap, s->d_first, s->d_ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st));
-        shade_kernel<<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
-                                                          s->rec_cap, s->d_colors, s->d_ctr);
+        if (p->max_depth == 0)
+            shade_kernel<false><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
+                                                                     s->rec_cap, s->d_colors, s->d_ctr);
+        else
+            shade_kernel<true><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
+                                                                    s->rec_cap, s->d_colors, s->d_ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
         merge_kernel<<<merge_blocks, MERGE_BLOCK, 0, st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
                                                           s->d_colors, s->d_first, d_rgb);
@@ -976,8 +1071,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     if (stats) {
         stats->primary_rays = npix;
         stats->hits = s->h_ctr->n_recs;
-        stats->shadow_rays = (uint64_t)s->h_ctr->n_recs * p->n_lights;
-        stats->shadow_tests = (uint64_t)s->h_ctr->leaf_prims * p->n_lights;
+        stats->shadow_rays = ((uint64_t)s->h_ctr->n_recs + s->h_ctr->bounce_hits) * p->n_lights;
+        stats->shadow_tests = ((uint64_t)s->h_ctr->leaf_prims + s->h_ctr->bounce_prims) * p->n_lights;
         stats->lit_samples = s->h_ctr->lit;
         stats->shadow_tests_run = s->h_ctr->tests_run;
         if (timing) {

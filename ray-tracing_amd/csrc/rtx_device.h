@@ -88,6 +88,7 @@ struct DFrame {
     uint32_t rows; // rows rendered by this call
     uint32_t stripe_rows, n_parts, part;
     uint32_t n_lights, seed;
+    uint32_t max_depth;
     float acne;
     f3 camera;
     f3 light_pos;
@@ -103,7 +104,9 @@ struct DCounters {
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
     unsigned long long lit;        // light samples that were not occluded
     unsigned long long tests_run;  // shadow-ray primitive tests executed
-    uint32_t pad1[24];
+    unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
+    unsigned long long bounce_prims; // sum of the leaf sizes over those
+    uint32_t pad1[20];
     // Work queue of the shading kernel, sharded eight ways so that the returning
     // atomic on one word (about 90 M/s chip-wide) does not pace the kernel: record i
     // belongs to shard i & 7; each head sits on a 128-byte line of its own.

@@ -201,6 +201,10 @@ FRAMES = [
     ("dino_spheres_480", "dino_spheres", 480, 270, 5, 3, False),
     ("buddha_384", "buddha", 384, 216, 4, 1, False),
     ("bunny_tile_1of3", "bunny", 320, 180, 6, 7, False),    # row tiling: part 1 of 3, stripes of 8
+    # mirror bounces (MAX_DEPTH > 0, raytracing.h:51-61) with the reference's reflect / RDM_Fresnel
+    ("default_bounce1", "default", 240, 240, 5, 2, False, 1),
+    ("spheres_bounce2", "spheres", 160, 160, 3, 4, False, 2),
+    ("multi_bounce3", "multi", 320, 180, 2, 6, False, 3),
 ]
 
 
@@ -226,14 +230,15 @@ def main():
         json.dump(structure, f, indent=1, sort_keys=True)
 
     frames = {}
-    for name, cfg, w, h, nl, seed, full in FRAMES:
+    for name, cfg, w, h, nl, seed, full, *rest in FRAMES:
         rb = op.RefBuilder()
         scenes.assemble(rb, cfg)
         p = capi.default_params(w, h, nl, seed)
+        p.max_depth = rest[0] if rest else 0
         if "tile" in name:
             p.stripe_rows, p.n_parts, p.part = 8, 3, 1
         rgb, fcol, hits, counts = rb.render(p)
-        frames[name] = dict(config=cfg, width=w, height=h, n_lights=nl, seed=seed,
+        frames[name] = dict(config=cfg, width=w, height=h, n_lights=nl, seed=seed, max_depth=p.max_depth,
                             stripe_rows=p.stripe_rows, n_parts=p.n_parts, part=p.part,
                             slab_tests=counts[0], leaf_visits=counts[1], hits=counts[2],
                             shadow_rays=counts[3], shaded_samples=counts[4],

@@ -19,6 +19,7 @@ with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as _
 def params_of(capi, fr):
     p = capi.default_params(fr["width"], fr["height"], fr["n_lights"], fr["seed"])
     p.stripe_rows, p.n_parts, p.part = fr["stripe_rows"], fr["n_parts"], fr["part"]
+    p.max_depth = fr.get("max_depth", 0)
     return p
 
 
@@ -92,6 +93,10 @@ def test_against_oracle(op, capi, built, cfg, w, h, nl, seed):
     assert np.array_equal(rgb2, rgb_g)
     assert stats.hits == st.hits and stats.shadow_tests == st.shadow_prim_tests
     assert stats.primary_rays == w * h and stats.shadow_rays == st.shadow_rays
+    # every occlusion decision agrees with the CPU (the screening of leaf triangles
+    # per record must not lose a blocker)
+    assert stats.lit_samples == st.shaded_samples
+    assert 0 < stats.shadow_tests_run <= stats.shadow_tests
 
 
 def test_other_box_depths_and_seeds(op, capi, built):
@@ -195,14 +200,38 @@ def test_packed_reciprocal_is_the_ieee_quotient(rtx):
     assert checked > 1.4e9 and bad == 0
 
 
+@pytest.mark.parametrize("cfg,w,h,nl,depth", [("default", 500, 500, 70, 1), ("spheres", 400, 400, 9, 4),
+                                               ("bunny", 640, 360, 130, 2), ("dino_spheres", 320, 180, 3, 8)])
+def test_mirror_bounces(op, capi, built, cfg, w, h, nl, depth):
+    """MAX_DEPTH > 0 (raytracing.h:51-61): reflect, trace the bounce in the same leaf,
+    add specular * Fresnel * bounce colour; every level draws its own light samples."""
+    _, d, sc = built(cfg)
+    p = capi.default_params(w, h, nl, 5)
+    p.max_depth = depth
+    rgb_g, hits_g = sc.render_hits(p)
+    rgb_c, _, hits_c, st = op.render(d, p)
+    assert st.bounce_rays > 0
+    check_hits(hits_g, hits_c)
+    check_rgb(rgb_g, rgb_c)
+    q = capi.default_params(w, h, nl, 5)
+    q.max_depth = depth
+    _, stats = sc.render(q)
+    assert stats.lit_samples == st.shaded_samples and stats.shadow_rays == st.shadow_rays
+
+
 def test_limits_are_errors(capi, rtx, built):
     _, d, sc = built("spheres")
     p = capi.default_params(16, 16, 70000, 1)
     with pytest.raises(rtx.RtxError) as e:
         sc.render(p)
     assert e.value.status == 5
+    p = capi.default_params(16, 16, 30000, 1)
+    p.max_depth = 2                      # 30000 * 3 sample indices do not fit 16 bits
+    with pytest.raises(rtx.RtxError) as e:
+        sc.render(p)
+    assert e.value.status == 5
     p = capi.default_params(16, 16, 1, 1)
-    p.max_depth = 1
+    p.max_depth = 9
     with pytest.raises(rtx.RtxError):
         sc.render(p)
 

@@ -21,6 +21,7 @@ with open(os.path.join(os.path.dirname(__file__), "golden", "frames.json")) as _
 def params_of(capi, fr):
     p = capi.default_params(fr["width"], fr["height"], fr["n_lights"], fr["seed"])
     p.stripe_rows, p.n_parts, p.part = fr["stripe_rows"], fr["n_parts"], fr["part"]
+    p.max_depth = fr.get("max_depth", 0)
     return p
 
 
