@@ -174,11 +174,16 @@ int rtx_device_count(void);
 /* Message for the calling thread's last failed call ("" if none). */
 const char *rtx_last_error(void);
 
-/* Device self-test with no counterpart in the reference: checks, for every binary32
- * value in its working range, that the packed reciprocal used inside the ray-triangle
- * test returns the bits of the correctly rounded IEEE quotient 1.f / a (the reference's
- * `f = 1.f / a`, intersect.h:41).  *checked = values compared, *mismatches must be 0. */
-rtx_status rtx_selftest(int device, uint64_t *checked, uint64_t *mismatches);
+/* Device self-test with no counterpart in the reference.  Two arithmetic shortcuts of
+ * the kernels are compared with the plain IEEE evaluation they replace:
+ *   out[0], out[1]  values checked / mismatches of the packed reciprocal against the
+ *                   correctly rounded quotient 1.f / a (the reference's `f = 1.f / a`,
+ *                   intersect.h:41), every binary32 value of its working range
+ *   out[2], out[3]  cases checked / mismatching cases of the closed form of the acne
+ *                   offset chain against the step-by-step float additions
+ *                   (raytracing.h:40); out[4] = cases the closed form declined
+ * Mismatches must be 0. */
+rtx_status rtx_selftest(int device, uint64_t out[5]);
 
 void rtx_params_default(rtx_params *p);
 /* Rows / pixels a call with these parameters renders (row tiling applied). */

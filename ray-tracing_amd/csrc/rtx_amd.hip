@@ -365,7 +365,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
         const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
         const uint32_t k_off = depth * fr.n_lights; // every bounce draws its own light samples
-        // lanes 0..2: running origin component and its increment
+        // shadow-ray origins: closed form where provably exact, else the serial chain run
+        // by lanes 0..2 (running origin component and its increment)
+        f3 dlt = f3_make(0.f, 0.f, 0.f);
+        const bool cx = acne_chain_delta(p0.x, step.x, fr.n_lights, dlt.x);
+        const bool cy = acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
+        const bool cz = acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
+        const bool closed = cx && cy && cz;
         float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
 
@@ -387,32 +393,40 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         // carries both rays through the triangle tests as packed pairs.
         for (uint32_t base = 0; base < fr.n_lights; base += PASS_SAMPLES) {
             const bool second = base + 64 < fr.n_lights; // wave-uniform: any sample in the upper half?
-            if (lane < 3) {
+            const uint32_t k1 = base + lane, k2 = k1 + 64;
+            const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
+            f3 p1, p2;
+            if (closed) {
+                const float s1 = (float)(k1 + 1u), s2 = (float)(k2 + 1u);
+                p1 = f3_make(p0.x + s1 * dlt.x, p0.y + s1 * dlt.y, p0.z + s1 * dlt.z);
+                p2 = f3_make(p0.x + s2 * dlt.x, p0.y + s2 * dlt.y, p0.z + s2 * dlt.z);
+            } else {
+                if (lane < 3) {
 #pragma unroll
-                for (int s = 0; s < 64; s++) {
-                    run = run + inc;
-                    L.chain[s * 3 + lane] = run;
-                }
-                if (second) {
-#pragma unroll
-                    for (int s = 64; s < PASS_SAMPLES; s++) {
+                    for (int s = 0; s < 64; s++) {
                         run = run + inc;
                         L.chain[s * 3 + lane] = run;
                     }
+                    if (second) {
+#pragma unroll
+                        for (int s = 64; s < PASS_SAMPLES; s++) {
+                            run = run + inc;
+                            L.chain[s * 3 + lane] = run;
+                        }
+                    }
                 }
+                wave_lds_sync();
+                p1 = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
+                p2 = p1;
+                if (second)
+                    p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
+                                 L.chain[(64 + lane) * 3 + 2]);
             }
-            wave_lds_sync();
-            const uint32_t k1 = base + lane, k2 = k1 + 64;
-            const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
-            const f3 p1 = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
-            f3 p2 = p1;
             f3 l1 = fr.light_pos, l2 = fr.light_pos;
             light_sample(fr.seed, pixel, leaf, k_off + k1, l1.x, l1.y);
             const f3 sd1 = f3_normalize(f3_sub(l1, p1)); // raytracing.h:43
             f3 sd2 = sd1;
             if (second) {
-                p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
-                             L.chain[(64 + lane) * 3 + 2]);
                 light_sample(fr.seed, pixel, leaf, k_off + k2, l2.x, l2.y);
                 sd2 = f3_normalize(f3_sub(l2, p2));
             }
@@ -492,7 +506,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         // ---- mirror bounce (raytracing.h:53-60) ----
         // the reflected ray starts from the hit position after all the acne steps
         f3 pos = p0;
-        if (fr.n_lights) {
+        if (fr.n_lights && closed) {
+            const float sn = (float)fr.n_lights;
+            pos = f3_make(p0.x + sn * dlt.x, p0.y + sn * dlt.y, p0.z + sn * dlt.z);
+        } else if (fr.n_lights) {
             const uint32_t slot = (fr.n_lights - 1) % PASS_SAMPLES;
             pos = f3_make(L.chain[slot * 3 + 0], L.chain[slot * 3 + 1], L.chain[slot * 3 + 2]);
         }
@@ -673,6 +690,47 @@ __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long 
     atomicAdd(checked, (unsigned long long)nc);
 }
 
+// acne_chain_delta against the serial chain on pseudo-random and adversarial inputs
+// (values next to powers of two, increments with few significant bits, both signs).
+__global__ void selftest_chain_kernel(unsigned long long *bad, unsigned long long *checked,
+                                      unsigned long long *refused) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w0 = id, w1 = 0x9E3779B9u, key = 0xC0FFEEu;
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long prod = (unsigned long long)0xD256D193u * w0;
+        w0 = (uint32_t)(prod >> 32) ^ key ^ w1;
+        w1 = (uint32_t)prod;
+        key += 0x9E3779B9u;
+    }
+    // p0: exponent 2^-12 .. 2^13, mantissa random or within a few ulps of a binade edge
+    const int e = (int)(w0 % 26u) - 12;
+    uint32_t man = (w0 >> 5) & 0x7FFFFFu;
+    const uint32_t mode = (w1 >> 3) & 7u;
+    if (mode == 0) man = (w0 >> 9) & 0x3Fu;              // just above 2^e
+    if (mode == 1) man = 0x7FFFFFu - ((w0 >> 9) & 0x3Fu); // just below 2^(e+1)
+    float p0 = __uint_as_float(((uint32_t)(e + 127) << 23) | man);
+    if (w1 & 1u) p0 = -p0;
+    // c: |c| 2^-24 .. 2^-1 times a random significand, sometimes cut to a few bits
+    uint32_t cm = (w1 >> 8) & 0x7FFFFFu;
+    if (mode >= 5) cm &= 0x7FFFFFu << (12 + (mode - 5) * 5);
+    float c = __uint_as_float(((uint32_t)(127 - 1 - (int)((w0 >> 28) + ((w1 >> 6) & 15u))) << 23) | cm);
+    if (w1 & 2u) c = -c;
+    const uint32_t n = 1u + (w0 >> 11) % 1000u;
+    float delta = 0.f;
+    const bool ok = acne_chain_delta(p0, c, n, delta);
+    uint32_t nb = 0;
+    if (ok) {
+        float run = p0;
+        for (uint32_t k = 1; k <= n; k++) {
+            run = run + c;
+            const float cf = p0 + (float)k * delta;
+            nb += __float_as_uint(run) != __float_as_uint(cf);
+        }
+    }
+    if (nb) atomicAdd(bad, 1ull);
+    atomicAdd(ok ? checked : refused, 1ull);
+}
+
 // ===========================================================================
 // Host side: scene upload and the C ABI
 // ===========================================================================
@@ -724,23 +782,28 @@ extern "C" int rtx_device_count(void) {
 
 extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
 
-extern "C" rtx_status rtx_selftest(int device, uint64_t *checked, uint64_t *mismatches) {
-    if (!checked || !mismatches) return fail(RTX_ERR_INVALID, "null argument");
+extern "C" rtx_status rtx_selftest(int device, uint64_t out[5]) {
+    if (!out) return fail(RTX_ERR_INVALID, "null argument");
     if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(device));
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 16));
-    hipError_t e = hipMemset(d, 0, 16);
+    HIP_TRY(hipMalloc((void **)&d, 40));
+    hipError_t e = hipMemset(d, 0, 40);
     if (e == hipSuccess) {
-        selftest_rcp_kernel<<<4096, 256>>>(d, d + 1);
+        selftest_rcp_kernel<<<4096, 256>>>(d + 1, d);
         e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) {
+            selftest_chain_kernel<<<16384, 256>>>(d + 3, d + 2, d + 4);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    unsigned long long h[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 40, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
-    *mismatches = h[0];
-    *checked = h[1];
+    for (int k = 0; k < 5; k++) out[k] = h[k];
     return RTX_OK;
 }
 

@@ -260,6 +260,34 @@ __device__ __forceinline__ bool out_of_scene(f3 c) {
     return c.x < 0.f || c.x > 1000.f || c.y < 0.f || c.y > 1000.f || c.z < 0.f || c.z > 1000.f;
 }
 
+// ---- running sum of the acne offset (raytracing.h:40) ---------------------------
+// The shadow-ray origin of sample k is p_k = fl(p_{k-1} + c) with p_0 the hit position
+// and c one component of normal * acne: a serial chain of rounded additions.  While
+// the running value stays inside one binade [2^e, 2^(e+1)) it is a multiple of the
+// binade's spacing u = 2^(e-23), and adding c rounds to the nearest multiple of u:
+// every step adds the same delta = u * rne(c / u), exactly, so p_k = p_0 + k * delta
+// with a single exact multiply and add.  That holds when c / u is not halfway between
+// integers (the rounding would then depend on the parity of p_k), k * delta is exact,
+// p_(n+1) still has p_0's sign and exponent (so no p_k, k <= n, leaves the binade),
+// and p_0 is not on the binade's lower edge heading towards zero.  Returns false when it cannot be guaranteed; the caller then runs the chain
+// step by step.  rtx_selftest() checks it against the serial chain.
+__device__ __forceinline__ bool acne_chain_delta(float p0, float c, uint32_t n, float &delta) {
+    const uint32_t bits = __float_as_uint(p0);
+    const uint32_t ex = (bits >> 23) & 0xFFu;
+    if (ex < 25u || ex > 250u) return false; // zero, subnormal, tiny, huge, inf, NaN
+    // exactly on the lower edge of its binade and moving towards zero: the sum falls
+    // into the finer grid below the edge even when it would round back to p_0 on u
+    if ((bits & 0x7FFFFFu) == 0u && ((__float_as_uint(c) ^ bits) >> 31) && c != 0.f) return false;
+    const float u = __uint_as_float((ex - 23u) << 23);
+    const float q = c / u; // exact: u is a power of two
+    if (!(__builtin_fabsf(q) * (float)(n + 1u) < 8388608.f)) return false;
+    const float r = __builtin_rintf(q);
+    if (__builtin_fabsf(q - r) == 0.5f) return false;
+    delta = r * u;
+    const float pend = p0 + (float)(n + 1u) * delta;
+    return (__float_as_uint(pend) >> 23) == (bits >> 23);
+}
+
 // ---- light sampler -------------------------------------------------------------
 // Philox-2x32-10, key = seed, counter = (pixel, leaf << 16 | sample); each
 // output word is mapped to 0..500 by a 32x32 -> high-32 multiply with 501.

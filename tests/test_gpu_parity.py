@@ -193,11 +193,15 @@ def test_record_buffer_growth(op, capi, rtx, scenes):
     sc.close()
 
 
-def test_packed_reciprocal_is_the_ieee_quotient(rtx):
+def test_arithmetic_shortcuts_are_exact(rtx):
     """intersect.h:41 `f = 1.f / a`: the kernel's packed reciprocal must return the bits
-    of the correctly rounded quotient for every float it is used for (exhaustive)."""
-    checked, bad = rtx.selftest(0)
-    assert checked > 1.4e9 and bad == 0
+    of the correctly rounded quotient for every float it is used for (exhaustive).
+    raytracing.h:40: the closed form of the running acne offset must equal the serial
+    float additions wherever it claims to apply."""
+    r = rtx.selftest(0)
+    assert r["rcp_checked"] > 1.4e9 and r["rcp_mismatches"] == 0
+    assert r["chain_checked"] > 1e6 and r["chain_mismatches"] == 0
+    assert r["chain_declined"] > 1000      # the hard cases exist in the sample and are declined
 
 
 @pytest.mark.parametrize("cfg,w,h,nl,depth", [("default", 500, 500, 70, 1), ("spheres", 400, 400, 9, 4),
