@@ -34,8 +34,16 @@
 #define MAX_NEST 24 // deepest box nesting the merge handles (checked at scene creation)
 
 // ---- trace ------------------------------------------------------------------
-// Pixels are dealt to waves as 8 x 8 tiles so that the 64 rays of a wave stay
-// close together in the box hierarchy.
+// One wave = the 64 primary rays of an 8 x 8 pixel tile.  The wave walks the pre-order
+// box array ONCE for all its rays: `n` is wave-uniform, lane l takes part in box n when
+// its own next box n_lane == n.  After an inner box the walk goes to n + 1 if any ray
+// entered it and to its skip link otherwise; a ray that missed an ancestor m waits
+// with n_lane = link(m), and because boxes nest, every waiting ray's link is at or
+// beyond the link of the box just missed, so the uniform walk can never step past a
+// waiting ray and visits exactly the union of the boxes its rays visit, each ray
+// seeing its own boxes in the reference's order (raytracing.h:74-98).  Box and
+// triangle data are therefore wave-uniform: scalar loads (next one already in flight),
+// used as SGPR operands; only the rays live in VGPRs.
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     DFrame fr, const DNode *__restrict__ nodes, uint32_t n_nodes, const DPrim *__restrict__ prims,
     DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
@@ -45,8 +53,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t i = bx * 16 + (wave & 1) * 8 + (lane & 7);
     const uint32_t r = by * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (i >= fr.width || r >= fr.rows) return;
-    const uint32_t j = part_row(fr, r);
+    const bool valid = i < fr.width && r < fr.rows;
+    if (!__any(valid) || n_nodes == 0) {
+        if (valid) first_rec[r * fr.width + i] = RTXD_NONE;
+        return;
+    }
+    const uint32_t j = part_row(fr, valid ? r : 0);
     const uint32_t pixel = j * fr.width + i;
     const uint32_t local = r * fr.width + i;
 
@@ -55,92 +67,100 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     const f3 inv = f3_make(1.f / d.x, 1.f / d.y, 1.f / d.z); // intersect.h:72-74
 
     uint32_t head = RTXD_NONE, prev = RTXD_NONE, ordinal = 0;
+    uint32_t n_lane = valid ? 0u : n_nodes; // lanes outside the frame never take part
     uint32_t n = 0;
+    DNode cur = nodes[0];
     while (n < n_nodes) {
-        const DNode nd = nodes[n];
-        const bool inner = nd.info == RTXD_NONE;
-        if (!box_hit(o, inv, nd.lb, nd.rt)) {
-            n = inner ? nd.link : n + 1;
-            continue;
-        }
-        if (inner) {
-            n = n + 1;
-            continue;
-        }
-        // leaf (intersect.h:95-132): every primitive is tested, the smallest
-        // distance wins, the earliest primitive on ties
-        const uint32_t first = nd.link, count = nd.info >> 16, leaf = nd.info & 0xFFFFu;
-        float best_t = 0.f;
-        uint32_t best = RTXD_NONE;
-#ifdef ABLATE_LEAF
-        if (count > 100000)
-#endif
-        {
-            // the next primitive's loads are issued before the current one is tested
-            const DPrim *p = prims + first;
-            f3 a = p->a, b = p->b, c = p->c;
-            uint32_t tm = p->type_mat;
-            for (uint32_t k = 0; k < count; k++) {
-                const DPrim *pn = prims + first + ((k + 1 < count) ? k + 1 : k);
-                const f3 na = pn->a, nb = pn->b, nc = pn->c;
-                const uint32_t ntm = pn->type_mat;
-                float t;
-                bool ok;
-                if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
-                    ok = tri_hit(o, d, a, b, c, t);
-                else
-                    ok = sph_hit(o, d, a, b.y, t);
-                if (ok && (best == RTXD_NONE || t < best_t)) {
-                    best_t = t;
-                    best = k;
+        const DNode ahead = nodes[(n + 1 < n_nodes) ? n + 1 : n]; // the likely next box
+        const bool mine = n_lane == n;
+        const bool hit = mine && box_hit(o, inv, cur.lb, cur.rt);
+        uint32_t next;
+        if (cur.info == RTXD_NONE) { // inner box
+            next = __any(hit) ? n + 1 : cur.link;
+            if (mine) n_lane = hit ? n + 1 : cur.link;
+        } else {
+            next = n + 1;
+            if (mine) n_lane = n + 1;
+            if (__any(hit)) {
+                // leaf (intersect.h:95-132): every primitive is tested, the smallest
+                // distance wins, the earliest primitive on ties
+                const uint32_t first = cur.link, count = cur.info >> 16, leaf = cur.info & 0xFFFFu;
+                const DPrim *__restrict__ lp = prims + first;
+                float best_t = 0.f;
+                uint32_t best = RTXD_NONE;
+                DPrim pc = lp[0];
+                for (uint32_t k = 0; k < count; k++) {
+                    const DPrim pn = lp[(k + 1 < count) ? k + 1 : k];
+                    if (hit) {
+                        float t;
+                        bool ok;
+                        if ((pc.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                            ok = tri_hit(o, d, pc.a, pc.b, pc.c, t);
+                        else
+                            ok = sph_hit(o, d, pc.a, pc.b.y, t);
+                        if (ok && (best == RTXD_NONE || t < best_t)) {
+                            best_t = t;
+                            best = k;
+                        }
+                    }
+                    pc = pn;
                 }
-                a = na;
-                b = nb;
-                c = nc;
-                tm = ntm;
+                const bool found = best != RTXD_NONE;
+                const unsigned long long fmask = __ballot(found);
+                if (fmask) {
+                    // one atomic per wave reserves the records of all rays that hit
+                    const uint32_t nfound = (uint32_t)__popcll(fmask);
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)fmask) - 1u) {
+                        base = atomicAdd(&ctr->n_recs, nfound);
+                        atomicAdd(&ctr->leaf_prims, (unsigned long long)count * nfound);
+                    }
+                    base = __shfl(base, __ffsll((long long)fmask) - 1);
+                    if (found) {
+                        const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
+                        const DPrim *p = lp + best;
+                        const f3 pos = f3_add(o, f3_scale(d, best_t)); // intersect.h:20, :58
+                        const uint32_t tm = p->type_mat;
+                        f3 nrm;
+                        if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                            nrm = p->n;
+                        else
+                            nrm = f3_normalize(f3_sub(pos, p->a)); // intersect.h:21
+                        if (idx < rec_cap) {
+                            DRec rc;
+                            rc.pixel = pixel;
+                            rc.node = n;
+                            rc.prim = p->id;
+                            rc.t = best_t;
+                            rc.px = pos.x;
+                            rc.py = pos.y;
+                            rc.pz = pos.z;
+                            rc.mat = tm >> 8;
+                            rc.nx = nrm.x;
+                            rc.ny = nrm.y;
+                            rc.nz = nrm.z;
+                            rc.next = RTXD_NONE;
+                            rc.leaf = leaf;
+                            rc.first = first;
+                            rc.count = count;
+                            rc.ordinal = ordinal;
+                            recs[idx] = rc;
+                            if (prev == RTXD_NONE)
+                                head = idx;
+                            else
+                                recs[prev].next = idx; // only this lane ever touches its own chain
+                            prev = idx;
+                        }
+                        ordinal++;
+                    }
+                }
             }
         }
-        if (best != RTXD_NONE) {
-            const DPrim *p = prims + first + best;
-            const f3 pos = f3_add(o, f3_scale(d, best_t)); // intersect.h:20, :58
-            const uint32_t tm = p->type_mat;
-            f3 nrm;
-            if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
-                nrm = p->n;
-            else
-                nrm = f3_normalize(f3_sub(pos, p->a)); // intersect.h:21
-            const uint32_t idx = atomicAdd(&ctr->n_recs, 1u);
-            atomicAdd(&ctr->leaf_prims, (unsigned long long)count);
-            if (idx < rec_cap) {
-                DRec rc;
-                rc.pixel = pixel;
-                rc.node = n;
-                rc.prim = p->id;
-                rc.t = best_t;
-                rc.px = pos.x;
-                rc.py = pos.y;
-                rc.pz = pos.z;
-                rc.mat = tm >> 8;
-                rc.nx = nrm.x;
-                rc.ny = nrm.y;
-                rc.nz = nrm.z;
-                rc.next = RTXD_NONE;
-                rc.leaf = leaf;
-                rc.first = first;
-                rc.count = count;
-                rc.ordinal = ordinal;
-                recs[idx] = rc;
-                if (prev == RTXD_NONE)
-                    head = idx;
-                else
-                    recs[prev].next = idx; // only this lane ever touches its own chain
-                prev = idx;
-            }
-            ordinal++;
-        }
-        n = n + 1;
+        cur = (next == n + 1) ? ahead : nodes[(next < n_nodes) ? next : n];
+        n = next;
     }
-    first_rec[local] = head;
+    if (valid) first_rec[local] = head;
 }
 
 // ---- shade.h -------------------------------------------------------------------
