@@ -96,6 +96,10 @@ struct Settings {
     rtx_params frame;               // width, height, n_lights, seed, acne, camera
     int box_depth = DEPTH_BOX;      // depth at which create_boxs stops splitting
     int device = 0;                 // HIP device used by render_image
+    std::vector<int> devices;       // if not empty: split the frame over these devices
+                                    // (row stripes, one host thread and one scene replica
+                                    // per entry; an id may repeat)
+    uint32_t stripe_rows = 8;       // rows per stripe of that split
     std::string output = "out.png"; // raytracing.h:140
     bool quiet = false;             // suppress the progress / "saved" messages
     Settings();

@@ -1,7 +1,7 @@
 // rt_main.cpp - command-line renderer: what the reference's main.cpp does (banner, scene,
 // render, timing), with the frame settings as options instead of #defines.
 //
-//   rt_main [--width W] [--height H] [--lights N] [--seed S] [--depth D] [--device G]
+//   rt_main [--width W] [--height H] [--lights N] [--seed S] [--depth D] [--device G] [--gpus N] [--bounces B]
 //           [--out FILE.png|.ppm]
 //
 // Run it from a directory that holds meshs/bunny.off and meshs/dino.off (scene.h:95-99).
@@ -23,6 +23,11 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(a, "--seed")) cfg.frame.seed = (uint32_t)std::atoi(v);
         else if (!std::strcmp(a, "--depth")) cfg.box_depth = std::atoi(v);
         else if (!std::strcmp(a, "--device")) cfg.device = std::atoi(v);
+        else if (!std::strcmp(a, "--gpus")) {  // split the frame over GPUs 0 .. N-1
+            cfg.devices.clear();
+            for (int g = 0; g < std::atoi(v); g++) cfg.devices.push_back(g);
+        }
+        else if (!std::strcmp(a, "--bounces")) cfg.frame.max_depth = (uint32_t)std::atoi(v);
         else if (!std::strcmp(a, "--out")) cfg.output = v;
         else {
             std::fprintf(stderr, "unknown option %s\n", a);

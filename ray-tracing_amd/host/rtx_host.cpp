@@ -14,6 +14,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <thread>
 
 // ---------------------------------------------------------------------------------------
 // small float helpers (vec3.h semantics: dot left to right, norm = sqrt(dot))
@@ -358,24 +359,75 @@ bool flatten(const Light &light, const Boxs &boxs, int box_depth, FlatScene &out
 // ---------------------------------------------------------------------------------------
 // rendering
 // ---------------------------------------------------------------------------------------
+// One part of the frame on one device (synchronous).  Returns "" or an error message.
+static std::string render_part(const rtx_scene_desc &d, int device, const rtx_params &p, uint8_t *out,
+                               rtx_stats *stats) {
+    rtx_scene *scene = nullptr;
+    if (rtx_scene_create(&d, device, &scene) != RTX_OK) return rtx_last_error();
+    std::string err;
+    if (rtx_render(scene, &p, out, stats) != RTX_OK) err = rtx_last_error();
+    rtx_scene_destroy(scene);
+    return err;
+}
+
 bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t> &rgb, rtx_stats *stats,
                       std::string *error) {
     Settings &cfg = settings();
     FlatScene flat;
     if (!flatten(light, boxs, cfg.box_depth, flat, error)) return false;
     const rtx_scene_desc d = flat.desc();
-    rtx_scene *scene = nullptr;
-    if (rtx_scene_create(&d, cfg.device, &scene) != RTX_OK) {
-        if (error) *error = rtx_last_error();
-        return false;
-    }
     rtx_params p = cfg.frame;
     p.stripe_rows = p.n_parts = p.part = 0;
-    rgb.resize((size_t)p.width * p.height * 3);
-    const rtx_status st = rtx_render(scene, &p, rgb.data(), stats);
-    if (st != RTX_OK && error) *error = rtx_last_error();
-    rtx_scene_destroy(scene);
-    return st == RTX_OK;
+    rgb.assign((size_t)p.width * p.height * 3, 0);
+    if (cfg.devices.size() <= 1) {
+        const std::string err = render_part(d, cfg.devices.empty() ? cfg.device : cfg.devices[0], p, rgb.data(), stats);
+        if (!err.empty() && error) *error = err;
+        return err.empty();
+    }
+    // Row stripes dealt round-robin to the devices: stripe s goes to part s % n_parts.
+    // Every part renders into a packed buffer of its own rows; the rows are then copied
+    // to their place in the frame.  The sampler is keyed by the global pixel index, so
+    // the frame does not depend on the split.
+    const uint32_t parts = (uint32_t)cfg.devices.size();
+    const uint32_t stripe = cfg.stripe_rows ? cfg.stripe_rows : 8;
+    std::vector<std::vector<uint8_t>> tiles(parts);
+    std::vector<std::string> errors(parts);
+    std::vector<rtx_stats> part_stats(parts);
+    std::vector<std::thread> workers;
+    for (uint32_t k = 0; k < parts; k++) {
+        workers.emplace_back([&, k]() {
+            rtx_params q = p;
+            q.stripe_rows = stripe;
+            q.n_parts = parts;
+            q.part = k;
+            tiles[k].resize((size_t)rtx_part_rows(&q) * q.width * 3);
+            errors[k] = render_part(d, cfg.devices[k], q, tiles[k].data(), &part_stats[k]);
+        });
+    }
+    for (std::thread &t : workers) t.join();
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    for (uint32_t k = 0; k < parts; k++) {
+        if (!errors[k].empty()) {
+            if (error) *error = errors[k];
+            return false;
+        }
+        const size_t row_bytes = (size_t)p.width * 3;
+        size_t src = 0;
+        for (uint32_t j = 0; j < p.height; j++) {
+            if ((j / stripe) % parts != k) continue;
+            std::memcpy(rgb.data() + (size_t)j * row_bytes, tiles[k].data() + src, row_bytes);
+            src += row_bytes;
+        }
+        if (stats) {
+            stats->primary_rays += part_stats[k].primary_rays;
+            stats->hits += part_stats[k].hits;
+            stats->shadow_rays += part_stats[k].shadow_rays;
+            stats->shadow_tests += part_stats[k].shadow_tests;
+            stats->lit_samples += part_stats[k].lit_samples;
+            stats->shadow_tests_run += part_stats[k].shadow_tests_run;
+        }
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------

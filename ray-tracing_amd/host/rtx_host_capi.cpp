@@ -145,13 +145,15 @@ int rtxh_build(void *h, rtx_scene_desc *out) {
     return 0;
 }
 
-// render_image() with run-time settings; path "" keeps the default out.png.
-int rtxh_render_image(void *h, const rtx_params *p, int device, const char *path) {
+// render_image() with run-time settings; path "" keeps the default out.png.  When
+// n_devices > 1 the frame is split over devices[0 .. n_devices) (ids may repeat).
+int rtxh_render_image(void *h, const rtx_params *p, const int *devices, uint32_t n_devices, const char *path) {
     HostBuilder *b = (HostBuilder *)h;
     rtx_host::Settings &cfg = rtx_host::settings();
     cfg.frame = *p;
     cfg.box_depth = b->box_depth;
-    cfg.device = device;
+    cfg.device = n_devices ? devices[0] : 0;
+    cfg.devices.assign(devices, devices + n_devices);
     cfg.quiet = true;
     if (path && *path) cfg.output = path;
     if (!b->split) {

@@ -33,7 +33,8 @@ def lib():
         L.rtxh_free.argtypes = [C.c_void_p]
         L.rtxh_init_scene.argtypes = [C.c_void_p, C.c_char_p]
         L.rtxh_build.argtypes = [C.c_void_p, C.POINTER(capi.SceneDesc)]
-        L.rtxh_render_image.argtypes = [C.c_void_p, C.POINTER(capi.Params), C.c_int, C.c_char_p]
+        L.rtxh_render_image.argtypes = [C.c_void_p, C.POINTER(capi.Params), C.POINTER(C.c_int), C.c_uint32,
+                                        C.c_char_p]
         L.rtxh_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
@@ -82,9 +83,12 @@ class HostBuilder:
         self.desc = d
         return d
 
-    def render_image(self, p, path, device=0):
-        """render_image() (raytracing.h:100): renders on the GPU and writes the file."""
-        if self.L.rtxh_render_image(self.h, C.byref(p), device, path.encode()):
+    def render_image(self, p, path, devices=(0,)):
+        """render_image() (raytracing.h:100): renders on the GPU(s) and writes the file.
+        More than one entry in `devices` splits the frame into row stripes, one host
+        thread and scene replica per entry (a device id may repeat)."""
+        devs = (C.c_int * len(devices))(*devices)
+        if self.L.rtxh_render_image(self.h, C.byref(p), devs, len(devices), path.encode()):
             raise RuntimeError("render_image failed")
 
     def close(self):

@@ -78,3 +78,15 @@ def test_no_gpu_is_an_error_not_a_fallback(rtx, capi, op, scenes):
     with pytest.raises(rtx.RtxError) as e:
         rtx.Scene(d)
     assert e.value.status == 2
+
+
+def test_host_library_exports_the_reference_entry_points():
+    """librtx_host.so must export the C++ functions of include/rtx_dropin.hpp with the
+    reference's signatures (scene.h:4, raytracing.h:100, meshs.h:1, :60, bvh.h:5)."""
+    import subprocess
+    lib = os.path.join(ROOT, "ray-tracing_amd", "host", "librtx_host.so")
+    out = subprocess.check_output(["nm", "-D", "--demangle", "--defined-only", lib], text=True)
+    for sig in ["init_scene(Light&, std::vector<Box", "render_image(Light&, std::vector<Box",
+                "parse(std::", "create_mesh(Mesh&, std::vector<Box", "create_boxs(std::vector<Box",
+                "rtx_host::flatten(", "rtx_host::render_to_memory(", "rtx_host::write_png("]:
+        assert sig in out, sig

@@ -1,6 +1,6 @@
 """GPU path (through the C ABI) against the CPU oracle and the golden frames.
 
-Bars (BASELINE north star): primary-hit primitive ids bit-exact; hit distances within
+Bars (north_star of BASELINE.json): primary-hit primitive ids bit-exact; hit distances within
 1e-4 relative (they are in fact required bit-exact here); final RGB within 1/255 on at
 least 99.9 % of the pixels.  The per-record colours are also compared (relative 1e-3:
 expf and the order of the per-sample sum differ between glibc and the GPU)."""
@@ -76,9 +76,9 @@ def test_golden_frames(op, capi, built, golden_dir, name):
 
 
 @pytest.mark.parametrize("cfg,w,h,nl,seed", [
-    ("bunny", 1920, 1080, 100, 1),          # BASELINE config 2 at full size
-    ("dino_spheres", 1920, 1080, 64, 2),
-    ("spheres", 1000, 1000, 4, 1),          # BASELINE config 1
+    ("bunny", 1920, 1080, 100, 1),          # BASELINE.json configs[1] at full size
+    ("dino_spheres", 1920, 1080, 500, 1),   # BASELINE.json configs[2] at full size
+    ("spheres", 1000, 1000, 4, 1),          # BASELINE.json configs[0]
     ("default", 1000, 1000, 1, 1),          # the reference as committed
     ("multi", 960, 540, 130, 3),            # sample count not a multiple of 64
 ])
@@ -148,7 +148,7 @@ def test_edge_shapes(op, capi, built):
 
 
 def test_row_tiles_are_split_invariant_at_full_size(capi, built):
-    """BASELINE config 2 frame size: rendering in 1, 2 and 8 parts gives the same frame,
+    """BASELINE.json configs[1] frame size: rendering in 1, 2 and 8 parts gives the same frame,
     and the same frame twice (determinism)."""
     _, d, sc = built("bunny")
     w, h, nl = 1920, 1080, 20
@@ -168,7 +168,7 @@ def test_row_tiles_are_split_invariant_at_full_size(capi, built):
 
 
 def test_buddha_4k_rows_sample(op, capi, built):
-    """BASELINE config 4 (buddha, 3840 x 2160, 500 samples): one part of 64 of the frame
+    """BASELINE.json configs[3] (buddha, 3840 x 2160, 500 samples): one part of 64 of the frame
     against the oracle, and the whole frame for determinism of the hit count."""
     _, d, sc = built("buddha")
     p = capi.default_params(3840, 2160, 500, 1)
@@ -266,3 +266,8 @@ def test_render_image_drop_in(op, capi, scenes, built, tmp_path):
     assert np.array_equal(img, rgb)
     rgb_c, _, _, _ = op.render(d, capi.default_params(300, 200, 6, 4))
     check_rgb(img, rgb_c)
+    # the same frame split into row stripes over three scene replicas (three host threads;
+    # on a one-GPU box all on device 0): the assembled file must be identical
+    path3 = str(tmp_path / "out3.png")
+    hb.render_image(p, path3, devices=(0, 0, 0))
+    assert open(path3, "rb").read() == data

@@ -126,7 +126,7 @@ def test_png_writer(host, tmp_path):
 @pytest.mark.skipif(not os.path.exists("/root/reference/main.cpp"), reason="reference tree not present")
 def test_reference_main_builds_against_the_drop_in(tmp_path):
     """The reference's main.cpp with its one include line switched to the drop-in header
-    (the edit INTEGRATION.md describes) compiles as C++11 and links against the two
+    (the one edit a maintainer makes) compiles as C++11 and links against the two
     libraries; nothing else in it changes."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
