@@ -135,6 +135,8 @@ typedef struct rtx_params {
 } rtx_params;
 
 #define RTX_FLAG_TIMING 1u /* fill rtx_stats::kernel_ms with HIP-event times */
+#define RTX_FLAG_WAVE_PER_HIT 2u /* always use the one-wave-per-hit shading kernel, also for
+                                    few light samples (for testing; results are identical) */
 
 /*
  * One (pixel, leaf) hit: the nearest primitive a primary ray hits inside one

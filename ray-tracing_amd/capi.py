@@ -10,6 +10,7 @@ RTX_NONE = 0xFFFFFFFF
 RTX_PRIM_SPHERE = 1
 RTX_PRIM_TRIANGLE = 2
 RTX_FLAG_TIMING = 1
+RTX_FLAG_WAVE_PER_HIT = 2
 
 STATUS_NAMES = {0: "RTX_OK", 1: "RTX_ERR_INVALID", 2: "RTX_ERR_NO_DEVICE", 3: "RTX_ERR_HIP",
                 4: "RTX_ERR_NOMEM", 5: "RTX_ERR_LIMIT"}

@@ -605,6 +605,92 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
     }
 }
 
+// ---- shadow + shade for few light samples ---------------------------------------
+// With n_lights <= G <= 32 (the reference as committed uses 1) a wave per hit record
+// would leave most lanes idle, so here a wave takes 64 / G records at once: lane
+// l handles sample l % G of record l / G, walks that record's leaf on its own (vector
+// loads, next primitive in flight) and the G lanes of a record are summed with the
+// same butterfly the one-record kernel uses, so both kernels return identical colours.
+// No mirror bounces (max_depth = 0 only).
+template <uint32_t G>
+__global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
+    DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
+    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
+    DCounters *__restrict__ ctr) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    const uint32_t per_wave = 64 / G;
+    const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
+    const float nl = (float)fr.n_lights;
+    const uint32_t k = lane % G;
+    uint32_t lit_total = 0;
+    unsigned long long tests_total = 0;
+    for (uint32_t base = wave_id * per_wave; base < n_recs; base += n_waves * per_wave) {
+        const uint32_t ridx = base + lane / G;
+        const bool live = ridx < n_recs && k < fr.n_lights;
+        f3 acc = f3_make(0.f, 0.f, 0.f);
+        bool lit = false;
+        if (live) {
+            const DRec *rc = recs + ridx;
+            const uint32_t pixel = rc->pixel, count = rc->count;
+            const DPrim *__restrict__ lp = prims + rc->first;
+            const f3 nrm = f3_make(rc->nx, rc->ny, rc->nz);
+            f3 p = f3_make(rc->px, rc->py, rc->pz);
+            f3 o, d;
+            primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+            const f3 step = f3_scale(nrm, fr.acne);
+            for (uint32_t s = 0; s <= k; s++) p = f3_add(p, step); // raytracing.h:40, k + 1 times
+            f3 lpos = fr.light_pos;
+            light_sample(fr.seed, pixel, rc->leaf, k, lpos.x, lpos.y);
+            const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
+            float tmin = 0.f;
+            bool any = false;
+            f3 a = lp->a, b = lp->b, c = lp->c;
+            uint32_t tm = lp->type_mat;
+            for (uint32_t q = 0; q < count; q++) {
+                const DPrim *pn = lp + ((q + 1 < count) ? q + 1 : q);
+                const f3 na = pn->a, nb = pn->b, nc = pn->c;
+                const uint32_t ntm = pn->type_mat;
+                float t;
+                bool ok;
+                if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                    ok = tri_hit(p, sd, a, b, c, t);
+                else
+                    ok = sph_hit(p, sd, a, b.y, t);
+                if (ok && (!any || t < tmin)) {
+                    tmin = t;
+                    any = true;
+                }
+                a = na;
+                b = nb;
+                c = nc;
+                tm = ntm;
+            }
+            tests_total += count;
+            if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
+                const DMat mat = mats[rc->mat];
+                const f3 col = shade(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat);
+                acc = f3_add(acc, f3_scale(f3_div(col, nl), 20.f)); // raytracing.h:48
+                lit = true;
+            }
+        }
+        lit_total += (uint32_t)__popcll(__ballot(lit));
+#pragma unroll
+        for (uint32_t off = G / 2; off >= 1; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, (int)off);
+            acc.y += __shfl_xor(acc.y, (int)off);
+            acc.z += __shfl_xor(acc.z, (int)off);
+        }
+        if (k == 0 && ridx < n_recs) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    }
+    // statistics: one atomic per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tests_total += __shfl_xor(tests_total, off);
+    if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
+    if (lane == 0 && tests_total) atomicAdd(&ctr->tests_run, tests_total);
+}
+
 // ---- merge -----------------------------------------------------------------------
 // vec3.h:97-101: a colour is "less" only if all three channels are strictly less.
 __device__ __forceinline__ bool all_less(float ax, float ay, float az, float bx, float by, float bz) {
@@ -1132,7 +1218,19 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
                                                     s->rec_cap, s->d_first, s->d_ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st));
-        if (p->max_depth == 0)
+#define LAUNCH_FEW(G) \
+    shade_few_kernel<G><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, \
+                                                              s->d_colors, s->d_ctr)
+        const uint32_t nlg = p->n_lights;
+        if (p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT)) {
+            // few samples: several hit records per wave
+            if (nlg <= 1) LAUNCH_FEW(1);
+            else if (nlg <= 2) LAUNCH_FEW(2);
+            else if (nlg <= 4) LAUNCH_FEW(4);
+            else if (nlg <= 8) LAUNCH_FEW(8);
+            else if (nlg <= 16) LAUNCH_FEW(16);
+            else LAUNCH_FEW(32);
+        } else if (p->max_depth == 0)
             shade_kernel<false><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
                                                                      s->rec_cap, s->d_colors, s->d_ctr);
         else

@@ -130,6 +130,22 @@ def test_light_heights_and_origin_drift(op, capi, scenes, rtx, light_z, acne, nl
     sc.close()
 
 
+@pytest.mark.parametrize("nl", [1, 2, 3, 4, 7, 8, 16, 25, 32, 33])
+def test_few_samples_kernel_equals_wave_per_hit_kernel(op, capi, built, nl):
+    """Up to 32 light samples a wave shades several hit records at once; it must return
+    the bits the one-record-per-wave kernel returns (and match the oracle)."""
+    _, d, sc = built("default")
+    p = capi.default_params(400, 400, nl, 2)
+    rgb_a, hits_a = sc.render_hits(p)
+    q = capi.default_params(400, 400, nl, 2)
+    q.flags |= capi.RTX_FLAG_WAVE_PER_HIT
+    rgb_b, hits_b = sc.render_hits(q)
+    assert hits_a.tobytes() == hits_b.tobytes() and np.array_equal(rgb_a, rgb_b)
+    rgb_c, _, hits_c, _ = op.render(d, p)
+    check_hits(hits_a, hits_c)
+    check_rgb(rgb_a, rgb_c)
+
+
 def test_edge_shapes(op, capi, built):
     """Tiny and ragged frames, zero samples, a frame that misses everything."""
     _, d, sc = built("default")

@@ -27,16 +27,20 @@ for name in names or ["bunny", "buddha"]:
     d = scenes.assemble(b, cfg)
     sc = rtx.Scene(d)
     import numpy as np
-    out = []
+    import time
+    out, wall = [], []
     for k in range(frames):
         p = rtx.default_params(w, h, nl, 1)
-        rgb, st = sc.render(p, timing=True)
+        t0 = time.perf_counter()
+        rgb, st = sc.render(p, timing=True)     # rtx_render: includes the read-back over PCIe
+        wall.append((time.perf_counter() - t0) * 1e3)
         out.append(list(st.kernel_ms))
     a = np.array(out)
     print("%-13s %dx%d N=%d hits=%d tests=%.3g lit=%d" % (name, w, h, nl, st.hits, st.shadow_tests, st.lit_samples))
     print("   trace ms ", " ".join("%.3f" % x for x in a[:, 0]))
     print("   shade ms ", " ".join("%.3f" % x for x in a[:, 1]))
     print("   merge ms ", " ".join("%.3f" % x for x in a[:, 2]))
+    print("   host wall ms incl. PCIe read-back ", " ".join("%.3f" % x for x in wall))
     med = np.median(a[:, 1])
     print("   shade median %.3f ms -> %.1f G tests/s (%.1f G run/s, %.1f %% of tests run), %.2f Grays/s shadow" %
           (med, st.shadow_tests / med / 1e6, st.shadow_tests_run / med / 1e6,
