@@ -164,57 +164,99 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
 }
 
 // ---- shade.h -------------------------------------------------------------------
+// The BSDF is pure colour arithmetic: nothing it computes feeds a hit, an occlusion or a
+// fold decision other than through the final colour, which is compared with the CPU to
+// 1/255.  Its divisions, square roots and the exponential therefore have two builds:
+// IEEE = true uses the correctly rounded operations (what the rest of the file uses),
+// IEEE = false the hardware's 1-ulp v_rcp / v_sqrt / v_exp, which is ~10x fewer
+// instructions per operation.  Everything that feeds a cancellation (the half vector,
+// the dot products, 1 - cos^2) is computed the same way in both builds, so the two
+// differ by a few ulp of the result, not by an amplified error.
+template <bool IEEE>
+struct Fm {
+    static __device__ __forceinline__ float div(float a, float b) {
+        if constexpr (IEEE) return a / b;
+        else return a * __builtin_amdgcn_rcpf(b);
+    }
+    static __device__ __forceinline__ float sqrt(float x) {
+        if constexpr (IEEE) return __builtin_sqrtf(x);
+        else return __builtin_amdgcn_sqrtf(x);
+    }
+    static __device__ __forceinline__ float exp(float x) {
+        if constexpr (IEEE) return expf(x);
+        else return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    }
+};
+
 // shade.h:7-18
+template <bool IEEE>
 __device__ __forceinline__ float rdm_beckmann(float NdotH, const DMat &m) {
     if (NdotH > 0.f) {
         float cos2 = NdotH * NdotH;
-        float tan2 = (1.f - cos2) / cos2;
+        float tan2 = Fm<IEEE>::div(1.f - cos2, cos2);
         float cos4 = cos2 * cos2;
-        return expf(-tan2 / m.alpha2) / (m.pi_alpha2 * cos4);
+        return Fm<IEEE>::div(Fm<IEEE>::exp(Fm<IEEE>::div(-tan2, m.alpha2)), m.pi_alpha2 * cos4);
     }
     return 0.f;
 }
 
 // shade.h:22-33 with extIOR = 1 (the only call site, shade.h:61); powf(x, 2)
 // is taken as x * x.
+template <bool IEEE>
 __device__ __forceinline__ float rdm_fresnel(float cosI, const DMat &m) {
     float sinT2 = m.ratio2 * (1.f - (cosI * cosI));
     if (sinT2 > 1.f) return 1.f;
-    float cosT = __builtin_sqrtf(1.f - sinT2);
+    float cosT = Fm<IEEE>::sqrt(1.f - sinT2);
     float a = cosI - cosT * m.ior, b = cosI + cosT * m.ior;
     float c = cosT - cosI * m.ior, e = cosT + cosI * m.ior;
-    float Rs = (a * a) / (b * b);
-    float Rp = (c * c) / (e * e);
+    float Rs = Fm<IEEE>::div(a * a, b * b);
+    float Rp = Fm<IEEE>::div(c * c, e * e);
     return 0.5f * (Rs + Rp);
 }
 
 // shade.h:35-47
+template <bool IEEE>
 __device__ __forceinline__ float rdm_g1(float DdotH, float DdotN, float alpha) {
-    float tn = __builtin_sqrtf(1.f - DdotN * DdotN) / DdotN;
-    float b = 1.f / (alpha * tn);
-    float k = DdotH / DdotN;
+    float tn = Fm<IEEE>::div(Fm<IEEE>::sqrt(1.f - DdotN * DdotN), DdotN);
+    float b = Fm<IEEE>::div(1.f, alpha * tn);
+    float k = Fm<IEEE>::div(DdotH, DdotN);
     if (k > 0.f) {
-        if (b < 1.6f) return (3.535f * b + 2.181f * b * b) / (1.f + 2.276f * b + 2.577f * b * b);
+        if (b < 1.6f)
+            return Fm<IEEE>::div(3.535f * b + 2.181f * b * b, 1.f + 2.276f * b + 2.577f * b * b);
         return 1.f;
     }
     return 0.f;
 }
 
-// shade.h:80-90 with RDM_bsdf, _s and _d inlined.  RDM_bsdf receives LdotH in
-// the place of LdotN (shade.h:88); the true LdotN is only the final cosine.
-__device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
+// shade.h:80-90 with RDM_bsdf, _s and _d inlined, times the per-sample weight
+// 20 / n_lights of raytracing.h:48.  RDM_bsdf receives LdotH in the place of LdotN
+// (shade.h:88); the true LdotN is only the final cosine.
+template <bool IEEE>
+__device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m, float nl) {
     f3 h = f3_normalize(f3_add(v, l));
     float LdotH = f3_dot(l, h);
     float VdotH = f3_dot(v, h);
     float NdotH = f3_dot(n, h);
     float LdotN = f3_dot(l, n);
     float VdotN = f3_dot(v, n);
-    float dd = rdm_beckmann(NdotH, m);
-    float ff = rdm_fresnel(LdotH, m);
-    float gg = rdm_g1(LdotH, LdotH, m.roughness) * rdm_g1(VdotH, VdotN, m.roughness);
-    f3 s = f3_div(f3_scale(f3_scale(f3_scale(m.spec, dd), ff), gg), 4.f * LdotH * VdotN);
+    float dd = rdm_beckmann<IEEE>(NdotH, m);
+    float ff = rdm_fresnel<IEEE>(LdotH, m);
+    float gg = rdm_g1<IEEE>(LdotH, LdotH, m.roughness) * rdm_g1<IEEE>(VdotH, VdotN, m.roughness);
+    const f3 num = f3_scale(f3_scale(f3_scale(m.spec, dd), ff), gg);
+    const float den = 4.f * LdotH * VdotN;
+    f3 s, c;
+    if constexpr (IEEE) {
+        s = f3_div(num, den);
+    } else {
+        s = f3_scale(num, __builtin_amdgcn_rcpf(den));
+    }
     f3 bsdf = f3_add(m.dif_pi, s);
-    return f3_scale(f3_mul(lc, bsdf), LdotN);
+    c = f3_scale(f3_mul(lc, bsdf), LdotN);
+    if constexpr (IEEE) {
+        return f3_scale(f3_div(c, nl), 20.f);
+    } else {
+        return f3_scale(f3_scale(c, __builtin_amdgcn_rcpf(nl)), 20.f);
+    }
 }
 
 // ---- shadow + shade ---------------------------------------------------------------
@@ -247,6 +289,12 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m) {
 #define PASS_SAMPLES 128 // light samples per pass: two per lane
 
 #define MAX_BOUNCES 8 // deepest mirror recursion (rtx_params::max_depth) the kernel folds
+
+// Register budget of shade_kernel: 5 waves per SIMD (96 VGPRs).  Measured on buddha
+// 3840x2160 / 500 samples: 4 waves (the compiler's own choice, 110 VGPRs) 5.12 ms,
+// 5 waves 4.87 ms, 6 waves 4.86 ms with three times the scratch traffic.  The build
+// with mirror bounces keeps the compiler's 3 waves (158 VGPRs) rather than spill.
+#define SHADE_WAVES_PER_SIMD 5
 
 struct ShadeLds {
     float4 level_sum[MAX_BOUNCES + 2];    // per bounce level: sum of its light samples
@@ -340,9 +388,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // BOUNCE = false is the build for max_depth = 0 (the reference as committed): the
-// mirror-bounce code and its registers are compiled out.
-template <bool BOUNCE>
-__global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
+// mirror-bounce code and its registers are compiled out.  IEEE selects the BSDF build.
+template <bool BOUNCE, bool IEEE>
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(BOUNCE ? 3 : SHADE_WAVES_PER_SIMD, BOUNCE ? 3 : SHADE_WAVES_PER_SIMD)))
+void shade_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
     const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
     DCounters *__restrict__ ctr) {
@@ -500,13 +549,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
             // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
             // samples of a lane are added in sample order
             if (live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))))) {
-                const f3 c = shade(nrm, view, sd1, fr.light_color, mat);
-                acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f)); // raytracing.h:48
+                acc = f3_add(acc, shade<IEEE>(nrm, view, sd1, fr.light_color, mat, nl)); // raytracing.h:48
                 lit++;
             }
             if (live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))))) {
-                const f3 c = shade(nrm, view, sd2, fr.light_color, mat);
-                acc = f3_add(acc, f3_scale(f3_div(c, nl), 20.f));
+                acc = f3_add(acc, shade<IEEE>(nrm, view, sd2, fr.light_color, mat, nl));
                 lit++;
             }
             wave_lds_sync();
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
         const f3 n2 = f3_scale(nrm, 2.f); // reflect(), vec3.h:103-106: I - N * 2.f * dot(N, I)
         const f3 rd = f3_normalize(f3_sub(d, f3_scale(n2, f3_dot(nrm, d))));
         const f3 ro = f3_add(pos, f3_scale(rd, fr.acne));
-        const float fres = rdm_fresnel(f3_dot(rd, nrm), mat);
+        const float fres = rdm_fresnel<true>(f3_dot(rd, nrm), mat);
         if (lane == 0) {
             const f3 w = f3_scale(mat.spec, fres);
             L.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);
@@ -612,7 +659,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_kernel(
 // loads, next primitive in flight) and the G lanes of a record are summed with the
 // same butterfly the one-record kernel uses, so both kernels return identical colours.
 // No mirror bounces (max_depth = 0 only).
-template <uint32_t G>
+template <uint32_t G, bool IEEE>
 __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
     const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
@@ -670,8 +717,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
             tests_total += count;
             if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
                 const DMat mat = mats[rc->mat];
-                const f3 col = shade(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat);
-                acc = f3_add(acc, f3_scale(f3_div(col, nl), 20.f)); // raytracing.h:48
+                acc = f3_add(acc, shade<IEEE>(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat, nl)); // raytracing.h:48
                 lit = true;
             }
         }
@@ -1218,10 +1264,20 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
                                                     s->rec_cap, s->d_first, s->d_ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st));
-#define LAUNCH_FEW(G) \
-    shade_few_kernel<G><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, \
-                                                              s->d_colors, s->d_ctr)
+#define LAUNCH_FEW(G)                                                                                        \
+    do {                                                                                                     \
+        if (ieee)                                                                                            \
+            shade_few_kernel<G, true><<<shade_blocks, SHADE_BLOCK, 0, st>>>(                                 \
+                fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);                    \
+        else                                                                                                 \
+            shade_few_kernel<G, false><<<shade_blocks, SHADE_BLOCK, 0, st>>>(                                \
+                fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);                    \
+    } while (0)
+#define LAUNCH_SHADE(B, I)                                                                                   \
+    shade_kernel<B, I><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,          \
+                                                             s->rec_cap, s->d_colors, s->d_ctr)
         const uint32_t nlg = p->n_lights;
+        const bool ieee = (p->flags & RTX_FLAG_IEEE_SHADE) != 0;
         if (p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT)) {
             // few samples: several hit records per wave
             if (nlg <= 1) LAUNCH_FEW(1);
@@ -1230,12 +1286,13 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             else if (nlg <= 8) LAUNCH_FEW(8);
             else if (nlg <= 16) LAUNCH_FEW(16);
             else LAUNCH_FEW(32);
-        } else if (p->max_depth == 0)
-            shade_kernel<false><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
-                                                                     s->rec_cap, s->d_colors, s->d_ctr);
-        else
-            shade_kernel<true><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,
-                                                                    s->rec_cap, s->d_colors, s->d_ctr);
+        } else if (p->max_depth == 0) {
+            if (ieee) LAUNCH_SHADE(false, true);
+            else LAUNCH_SHADE(false, false);
+        } else {
+            if (ieee) LAUNCH_SHADE(true, true);
+            else LAUNCH_SHADE(true, false);
+        }
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
         merge_kernel<<<merge_blocks, MERGE_BLOCK, 0, st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
                                                           s->d_colors, s->d_first, d_rgb);

@@ -146,6 +146,41 @@ def test_few_samples_kernel_equals_wave_per_hit_kernel(op, capi, built, nl):
     check_rgb(rgb_a, rgb_c)
 
 
+@pytest.mark.parametrize("cfg,w,h,nl,depth", [
+    ("spheres", 400, 400, 48, 0),      # nickel: roughness 0.01, the sharpest highlight
+    ("multi", 480, 270, 200, 0),
+    ("default", 300, 300, 3, 0),       # few-samples kernel
+    ("spheres", 200, 200, 40, 2),      # mirror bounces
+])
+def test_ieee_shading_flag(op, capi, built, cfg, w, h, nl, depth):
+    """The BSDF runs on the hardware's 1-ulp reciprocal / square root / exp2 by default and
+    on correctly rounded operations with RTX_FLAG_IEEE_SHADE.  Hits and occlusion decisions
+    are the same in both builds, colours differ by a few ulp, and both are within the bar
+    of the CPU."""
+    _, d, sc = built(cfg)
+    p = capi.default_params(w, h, nl, 5)
+    p.max_depth = depth
+    rgb_f, hits_f = sc.render_hits(p)
+    _, st_f = sc.render(p)
+    q = capi.default_params(w, h, nl, 5)
+    q.max_depth = depth
+    q.flags |= capi.RTX_FLAG_IEEE_SHADE
+    rgb_i, hits_i = sc.render_hits(q)
+    _, st_i = sc.render(q)
+    for k in ("pixel", "ordinal", "leaf", "prim"):
+        assert np.array_equal(hits_f[k], hits_i[k]), k
+    assert np.array_equal(hits_f["t"].view(np.uint32), hits_i["t"].view(np.uint32))
+    assert st_f.lit_samples == st_i.lit_samples and st_f.shadow_tests_run == st_i.shadow_tests_run
+    rel = np.abs(hits_f["color"] - hits_i["color"]) / (np.abs(hits_i["color"]) + 1e-2)
+    assert rel.max() < 2e-4, rel.max()
+    assert np.abs(rgb_f.astype(np.int32) - rgb_i.astype(np.int32)).max() <= 1
+    rgb_c, _, hits_c, _ = op.render(d, p)
+    check_hits(hits_i, hits_c)
+    check_hits(hits_f, hits_c)
+    check_rgb(rgb_i, rgb_c)
+    check_rgb(rgb_f, rgb_c)
+
+
 def test_edge_shapes(op, capi, built):
     """Tiny and ragged frames, zero samples, a frame that misses everything."""
     _, d, sc = built("default")

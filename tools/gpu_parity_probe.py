@@ -27,3 +27,22 @@ cmp("default",1000,1000,1)
 cmp("default",250,250,8)
 cmp("multi",384,216,70,seed=2)
 cmp("bunny",1920,1080,100)
+
+
+def ieee_vs_fast(cfg, W, H, N, seed=1, depth=0):
+    ob = op.OracleBuilder(10); d = scenes.assemble(ob, cfg)
+    sc = rtx.Scene(d)
+    p = capi.default_params(W, H, N, seed); p.max_depth = depth
+    rgb_f, h_f = sc.render_hits(p)
+    p2 = capi.default_params(W, H, N, seed); p2.max_depth = depth; p2.flags |= capi.RTX_FLAG_IEEE_SHADE
+    rgb_i, h_i = sc.render_hits(p2)
+    rel = (np.abs(h_f["color"] - h_i["color"]) / (np.abs(h_i["color"]) + 1e-2)).max()
+    diff = np.abs(rgb_f.astype(int) - rgb_i.astype(int)).max(axis=2)
+    print("ieee vs fast", cfg, W, H, N, "depth", depth, "max rel colour diff %.3g" % rel,
+          "rgb equal %.5f%% maxdiff %d" % (100 * (diff == 0).mean(), diff.max()))
+
+
+ieee_vs_fast("spheres", 500, 500, 64)
+ieee_vs_fast("dino_spheres", 960, 540, 200)
+ieee_vs_fast("multi", 960, 540, 300)
+ieee_vs_fast("spheres", 300, 300, 40, depth=2)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times of a workload, frame by frame (GPU box).
-usage: kernel_times.py [workload ...] [--frames N]"""
+usage: kernel_times.py [workload ...] [--frames N] [--ieee]"""
 import importlib
 import os
 import sys
@@ -13,12 +13,15 @@ host = importlib.import_module("ray-tracing_amd.host_py")
 import bench  # noqa: E402
 
 frames = 8
+flags = 0
 names = []
 args = sys.argv[1:]
 while args:
     a = args.pop(0)
     if a == "--frames":
         frames = int(args.pop(0))
+    elif a == "--ieee":
+        flags |= rtx.capi.RTX_FLAG_IEEE_SHADE
     else:
         names.append(a)
 for name in names or ["bunny", "buddha"]:
@@ -31,6 +34,7 @@ for name in names or ["bunny", "buddha"]:
     out, wall = [], []
     for k in range(frames):
         p = rtx.default_params(w, h, nl, 1)
+        p.flags |= flags
         t0 = time.perf_counter()
         rgb, st = sc.render(p, timing=True)     # rtx_render: includes the read-back over PCIe
         wall.append((time.perf_counter() - t0) * 1e3)
