@@ -142,6 +142,11 @@ typedef struct rtx_params {
                                     reciprocal / square root / exp2.  Hits, distances and
                                     occlusion decisions are the same either way; colours differ
                                     by a few ulp.  About 15 % slower at 500 light samples. */
+#define RTX_FLAG_NO_SORT 8u      /* shade every hit record with the plain kernel (light samples in
+                                    index order); by default records with a large leaf and more
+                                    than 128 light samples go to a second kernel that sorts the
+                                    samples by light cell.  Same hits and occlusion decisions;
+                                    colours differ by the order of the per-sample sum. */
 
 /*
  * One (pixel, leaf) hit: the nearest primitive a primary ray hits inside one

@@ -89,6 +89,7 @@ struct DFrame {
     uint32_t stripe_rows, n_parts, part;
     uint32_t n_lights, seed;
     uint32_t max_depth;
+    uint32_t sort_samples; // records with large leaves are shaded with sorted light samples
     float acne;
     f3 camera;
     f3 light_pos;
@@ -107,13 +108,18 @@ struct DCounters {
     unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
     unsigned long long bounce_prims; // sum of the leaf sizes over those
     uint32_t pad1[20];
-    // Work queue of the shading kernel, sharded eight ways so that the returning
-    // atomic on one word (about 90 M/s chip-wide) does not pace the kernel: record i
-    // belongs to shard i & 7; each head sits on a 128-byte line of its own.
+    // Work lists of the shading kernel (one per class of record): length, and the work
+    // queue over it, sharded eight ways so that the returning atomic on one word (a few
+    // tens of millions per second chip-wide) does not pace the kernel: entry e belongs to
+    // head e & 7; every word that is hit by atomics sits on a 128-byte line of its own.
+    struct {
+        uint32_t count;
+        uint32_t pad[31];
+    } cls[4];
     struct {
         uint32_t next;
         uint32_t pad[31];
-    } head[8];
+    } head[4][8];
 };
 
 // ---- vec3.h -----------------------------------------------------------------
@@ -291,8 +297,9 @@ __device__ __forceinline__ bool acne_chain_delta(float p0, float c, uint32_t n, 
 // ---- light sampler -------------------------------------------------------------
 // Philox-2x32-10, key = seed, counter = (pixel, leaf << 16 | sample); each
 // output word is mapped to 0..500 by a 32x32 -> high-32 multiply with 501.
-__device__ __forceinline__ void light_sample(uint32_t seed, uint32_t pixel, uint32_t leaf,
-                                             uint32_t k, float &lx, float &ly) {
+// The two integers 0..500 of sample k (the reference's dist(gen), raytracing.h:38-39).
+__device__ __forceinline__ void light_sample_u(uint32_t seed, uint32_t pixel, uint32_t leaf,
+                                               uint32_t k, uint32_t &ux, uint32_t &uy) {
     uint32_t c0 = pixel, c1 = (leaf << 16) | k, key = seed;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
@@ -302,8 +309,16 @@ __device__ __forceinline__ void light_sample(uint32_t seed, uint32_t pixel, uint
         c1 = lo;
         key += 0x9E3779B9u;
     }
-    lx = 250.f + (float)__umulhi(c0, 501u); // raytracing.h:38
-    ly = 250.f + (float)__umulhi(c1, 501u); // raytracing.h:39
+    ux = __umulhi(c0, 501u);
+    uy = __umulhi(c1, 501u);
+}
+
+__device__ __forceinline__ void light_sample(uint32_t seed, uint32_t pixel, uint32_t leaf,
+                                             uint32_t k, float &lx, float &ly) {
+    uint32_t ux, uy;
+    light_sample_u(seed, pixel, leaf, k, ux, uy);
+    lx = 250.f + (float)ux; // raytracing.h:38
+    ly = 250.f + (float)uy; // raytracing.h:39
 }
 
 // ---- primary ray (raytracing.h:119-121) ----------------------------------------
