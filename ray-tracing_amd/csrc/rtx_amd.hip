@@ -300,7 +300,9 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m, floa
 // A wave takes this many records of a queue per atomic.  Returning atomics on one
 // address complete at only a few tens of millions per second, which is the same order
 // as the record rate of a frame with few light samples.
-#define QUEUE_BATCH 4u
+#ifndef QUEUE_BATCH
+#define QUEUE_BATCH 2u
+#endif
 
 // Work classes, in the order the shading kernel takes them.  Records with a leaf of
 // SORT_MIN_LEAF..CAND_MAX primitives, more than one pass of light samples and the closed
@@ -310,9 +312,13 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m, floa
 #define CLASS_SORTED_LIGHT 1u
 #define CLASS_PLAIN_HEAVY 2u
 #define CLASS_PLAIN_LIGHT 3u
-#define CLASS_HEAVY_LEAF 128u // leaf size from which a record counts as heavy
+#ifndef CLASS_HEAVY_LEAF
+#define CLASS_HEAVY_LEAF 96u  // leaf size from which a record counts as heavy
+#endif
 #define SORT_MIN_LIGHTS 129   // fewer samples are a single pass: nothing to gain
-#define SORT_MIN_LEAF 40u     // smaller leaves leave too few candidates for the sort to pay
+#ifndef SORT_MIN_LEAF
+#define SORT_MIN_LEAF 12u     // smaller leaves leave too few candidates for the sort to pay
+#endif
 
 // The work lists (record numbers) lie behind the rec_cap colours, rec_cap entries each.
 __device__ __forceinline__ uint32_t *work_list(float4 *colors, uint32_t rec_cap, uint32_t cls) {
@@ -680,8 +686,12 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
 // samples of that order, i.e. a few neighbouring cells, and walks only the candidates
 // whose mask meets those cells.  A sample's origin follows from its index alone (closed
 // form of the acne chain), so the order of the samples is free.
+#ifndef SORT_MAX
 #define SORT_MAX 512        // samples sorted at a time
-#define SORT_MIN_CAND 12    // with fewer candidates the sort costs more than it saves
+#endif
+#ifndef SORT_MIN_CAND
+#define SORT_MIN_CAND 10    // with fewer candidates the sort costs more than it saves
+#endif
 
 // cell (cx, cy) -> position along the Hilbert curve, one nibble per cell, cell = cy * 4 + cx
 #define HILBERT_OF_CELL 0xA965B874CD23FE10ull
@@ -1071,7 +1081,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
 // The record goes to the list of its class.  A wave classifies CLASSIFY_PER_LANE x 64
 // records and then reserves their entries with one atomic per class (returning atomics
 // on one address are slow: one per 64 records would cost more than the rest of the kernel).
+#ifndef CLASSIFY_PER_LANE
 #define CLASSIFY_PER_LANE 8
+#endif
 __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__restrict__ recs,
                                                         uint32_t rec_cap, float4 *__restrict__ colors,
                                                         DCounters *__restrict__ ctr) {
