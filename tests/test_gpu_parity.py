@@ -206,7 +206,7 @@ def test_sorted_sampling_flag(op, capi, built, cfg, w, h, nl):
     assert st_s.lit_samples == st_u.lit_samples
     # (the two screens have slightly different margins; with few candidates per record
     # nothing is sorted and the counts are nearly the same)
-    assert st_s.shadow_tests_run <= 1.02 * st_u.shadow_tests_run <= 1.02 * st_u.shadow_tests
+    assert st_s.shadow_tests_run <= 1.05 * st_u.shadow_tests_run <= 1.05 * st_u.shadow_tests
     if cfg in ("buddha", "multi"):
         assert st_s.shadow_tests_run < 0.9 * st_u.shadow_tests_run
     rel = np.abs(hits_s["color"] - hits_u["color"]) / (np.abs(hits_u["color"]) + 1e-2)
