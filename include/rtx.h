@@ -174,7 +174,8 @@ typedef struct rtx_stats {
     uint64_t shadow_tests_run; /* of shadow_tests, those the GPU actually executed;
                                the rest were ruled out per record by a conservative
                                geometric screen and cannot affect a result */
-    float kernel_ms[4];     /* trace, shadow+shade, merge, total on the stream
+    float kernel_ms[4];     /* trace (with the sorting of the hit records into work
+                               lists), shadow+shade kernel, merge, total on the stream
                                (only with RTX_FLAG_TIMING) */
 } rtx_stats;
 

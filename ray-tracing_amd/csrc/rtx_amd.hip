@@ -1833,7 +1833,6 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
         trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
                                                     s->rec_cap, s->d_first, s->d_ctr);
-        if (timing) HIP_TRY(hipEventRecord(s->ev[1], st));
 #define LAUNCH_FEW(G)                                                                                        \
     do {                                                                                                     \
         if (ieee)                                                                                            \
@@ -1851,6 +1850,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         const bool few = p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
         if (!few)
             classify_kernel<<<few_blocks, 256, 0, st>>>(fr, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);
+        if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
         if (few) {
             // few samples: several hit records per wave
             if (nlg <= 1) LAUNCH_FEW(1);

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Measurements behind profiles/: bench lines of every workload, rocprofv3 kernel stats of
+# the default bench command, and PMC passes (SQ, FETCH_SIZE, WRITE_SIZE: one run each).
+# Run on the GPU box from the repo root; results go to gpurun_out/round/.
+set -o pipefail
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/round
+mkdir -p $O
+for w in buddha bunny dino_spheres multi default; do
+    echo "bench $w"
+    timeout -k 10 300 python -u bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err || exit 1
+done
+cd /tmp
+echo "rocprofv3 kernel stats"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+echo "pmc sq"
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $O/pmc_sq --output-format csv -- python3 $R/tools/kernel_times.py buddha --frames 2 > $O/pmc_sq.log 2>&1 || exit 1
+echo "pmc fetch"
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch --output-format csv -- python3 $R/tools/kernel_times.py buddha --frames 2 > $O/pmc_fetch.log 2>&1 || exit 1
+echo "pmc write"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- python3 $R/tools/kernel_times.py buddha --frames 2 > $O/pmc_write.log 2>&1 || exit 1
+cd $R
+python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq.txt
+python tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch.txt
+python tools/pmc_summary.py $O/pmc_write > $O/pmc_write.txt
+echo done
