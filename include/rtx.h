@@ -187,7 +187,7 @@ int rtx_device_count(void);
 /* Message for the calling thread's last failed call ("" if none). */
 const char *rtx_last_error(void);
 
-/* Device self-test with no counterpart in the reference.  Two arithmetic shortcuts of
+/* Device self-test with no counterpart in the reference.  Three arithmetic shortcuts of
  * the kernels are compared with the plain IEEE evaluation they replace:
  *   out[0], out[1]  values checked / mismatches of the packed reciprocal against the
  *                   correctly rounded quotient 1.f / a (the reference's `f = 1.f / a`,
@@ -195,8 +195,11 @@ const char *rtx_last_error(void);
  *   out[2], out[3]  cases checked / mismatching cases of the closed form of the acne
  *                   offset chain against the step-by-step float additions
  *                   (raytracing.h:40); out[4] = cases the closed form declined
+ *   out[5], out[6]  values checked / mismatches of the packed division by a shared
+ *                   denominator and of the two-vector normalisation built on it against
+ *                   `v / sqrt(dot(v, v))` (vec3.h:28-31)
  * Mismatches must be 0. */
-rtx_status rtx_selftest(int device, uint64_t out[5]);
+rtx_status rtx_selftest(int device, uint64_t out[7]);
 
 void rtx_params_default(rtx_params *p);
 /* Rows / pixels a call with these parameters renders (row tiling applied). */

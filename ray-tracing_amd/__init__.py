@@ -38,7 +38,7 @@ def lib():
         L.rtx_params_default.argtypes = [C.POINTER(Params)]
         L.rtx_part_rows.restype = C.c_uint32
         L.rtx_part_rows.argtypes = [C.POINTER(Params)]
-        L.rtx_selftest.argtypes = [C.c_int, C.c_uint64 * 5]
+        L.rtx_selftest.argtypes = [C.c_int, C.c_uint64 * 7]
         L.rtx_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.rtx_scene_destroy.argtypes = [C.c_void_p]
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
@@ -61,10 +61,11 @@ def device_count():
 
 def selftest(device=0):
     """rtx_selftest: dict of the checked / mismatch counts (mismatches must be 0)."""
-    out = (C.c_uint64 * 5)()
+    out = (C.c_uint64 * 7)()
     _check(lib().rtx_selftest(device, out))
     return dict(rcp_checked=int(out[0]), rcp_mismatches=int(out[1]), chain_checked=int(out[2]),
-                chain_mismatches=int(out[3]), chain_declined=int(out[4]))
+                chain_mismatches=int(out[3]), chain_declined=int(out[4]), div_checked=int(out[5]),
+                div_mismatches=int(out[6]))
 
 
 class Scene:

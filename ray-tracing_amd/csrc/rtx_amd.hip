@@ -28,6 +28,9 @@
 // ===========================================================================
 
 #define TRACE_BLOCK 256
+#ifndef TRACE_BLOCKS_PER_CU
+#define TRACE_BLOCKS_PER_CU 8 // resident blocks of trace_kernel per CU (8 waves per SIMD)
+#endif
 #define SHADE_BLOCK 256
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define MERGE_BLOCK 256
@@ -49,14 +52,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
     DCounters *__restrict__ ctr) {
     const uint32_t tiles_x = (fr.width + 15) / 16;
-    const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const uint32_t n_tiles = tiles_x * ((fr.rows + 15) / 16);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the block appends its hit records to one shard of the record array
+    const uint32_t shard = blockIdx.x % REC_SHARDS, shard_cap = rec_cap / REC_SHARDS;
+    unsigned long long leaf_prims = 0;
+    // a block takes the 16 x 16 pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
     const uint32_t i = bx * 16 + (wave & 1) * 8 + (lane & 7);
     const uint32_t r = by * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool valid = i < fr.width && r < fr.rows;
     if (!__any(valid) || n_nodes == 0) {
         if (valid) first_rec[r * fr.width + i] = RTXD_NONE;
-        return;
+        continue;
     }
     const uint32_t j = part_row(fr, valid ? r : 0);
     const uint32_t pixel = j * fr.width + i;
@@ -111,14 +120,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                     // one atomic per wave reserves the records of all rays that hit
                     const uint32_t nfound = (uint32_t)__popcll(fmask);
                     uint32_t base = 0;
-                    if (lane == (uint32_t)__ffsll((long long)fmask) - 1u) {
-                        base = atomicAdd(&ctr->n_recs, nfound);
-                        atomicAdd(&ctr->leaf_prims, (unsigned long long)count * nfound);
-                    }
+                    if (lane == (uint32_t)__ffsll((long long)fmask) - 1u)
+                        base = atomicAdd(&ctr->shard[shard].count, nfound);
+                    leaf_prims += (unsigned long long)count * nfound;
                     base = __shfl(base, __ffsll((long long)fmask) - 1);
                     if (found) {
-                        const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
+                        const uint32_t idx = shard * shard_cap + slot;
                         const DPrim *p = lp + best;
                         const f3 pos = f3_add(o, f3_scale(d, best_t)); // intersect.h:20, :58
                         const uint32_t tm = p->type_mat;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                             nrm = p->n;
                         else
                             nrm = f3_normalize(f3_sub(pos, p->a)); // intersect.h:21
-                        if (idx < rec_cap) {
+                        if (slot < shard_cap) {
                             DRec rc;
                             rc.pixel = pixel;
                             rc.node = n;
@@ -161,6 +170,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
         n = next;
     }
     if (valid) first_rec[local] = head;
+    } // tiles
+    if (lane == 0 && leaf_prims) atomicAdd(&ctr->leaf_prims, leaf_prims);
 }
 
 // ---- shade.h -------------------------------------------------------------------
@@ -256,6 +267,110 @@ __device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m, floa
         return f3_scale(f3_div(c, nl), 20.f);
     } else {
         return f3_scale(f3_scale(c, __builtin_amdgcn_rcpf(nl)), 20.f);
+    }
+}
+
+// The fast build of the BSDF, written once for one sample (T = float) and for the two
+// samples of a lane (T = v2f, packed arithmetic; lx, ly, lz are the unit directions to the
+// light): the same operations either way, so both give the same bits.  The half vector
+// and the dot products are computed exactly as shade() computes them, the rest is
+// regrouped around fewer hardware reciprocals (tan^2 and 1/cos^4 share one, the two
+// Fresnel quotients are squared after the division, G1 takes one reciprocal square root,
+// and G1 of the view direction depends on the sample only through a sign).  Same special
+// cases as shade.h: D = 0 for NdotH <= 0, F = 1 beyond the critical angle, G1 = 0 unless
+// DdotH / DdotN > 0, = 1 for b >= 1.6 or NaN.
+__device__ __forceinline__ float rcp_t(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ v2f rcp_t(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ float sqrt_t(float a) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ v2f sqrt_t(v2f a) { return (v2f){__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }
+__device__ __forceinline__ float rsq_t(float a) { return __builtin_amdgcn_rsqf(a); }
+__device__ __forceinline__ v2f rsq_t(v2f a) { return (v2f){__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
+__device__ __forceinline__ float exp2_t(float a) { return __builtin_amdgcn_exp2f(a); }
+__device__ __forceinline__ v2f exp2_t(v2f a) { return (v2f){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+// c > th ? a : b and c < th ? a : b, per element
+__device__ __forceinline__ float if_gt(float c, float th, float a, float b) { return c > th ? a : b; }
+__device__ __forceinline__ v2f if_gt(v2f c, float th, v2f a, v2f b) {
+    return (v2f){c.x > th ? a.x : b.x, c.y > th ? a.y : b.y};
+}
+__device__ __forceinline__ float if_lt(float c, float th, float a, float b) { return c < th ? a : b; }
+__device__ __forceinline__ v2f if_lt(v2f c, float th, v2f a, v2f b) {
+    return (v2f){c.x < th ? a.x : b.x, c.y < th ? a.y : b.y};
+}
+__device__ __forceinline__ void normalize_t(float &x, float &y, float &z) {
+    const f3 h = f3_normalize(f3_make(x, y, z));
+    x = h.x;
+    y = h.y;
+    z = h.z;
+}
+__device__ __forceinline__ void normalize_t(v2f &x, v2f &y, v2f &z) { normalize2(x, y, z); }
+
+template <typename T>
+__device__ __forceinline__ void bsdf_fast(f3 n, f3 v, T lx, T ly, T lz, f3 lc, const DMat &m, float nl, T &rx,
+                                          T &ry, T &rz) {
+    const T zero = lx - lx, one = zero + 1.f;
+    T hx = v.x + lx, hy = v.y + ly, hz = v.z + lz;
+    normalize_t(hx, hy, hz);
+    const T LdotH = lx * hx + ly * hy + lz * hz;
+    const T VdotH = v.x * hx + v.y * hy + v.z * hz;
+    const T NdotH = n.x * hx + n.y * hy + n.z * hz;
+    const T LdotN = lx * n.x + ly * n.y + lz * n.z;
+    const float VdotN = f3_dot(v, n);
+    // Beckmann (shade.h:7-18)
+    const T cos2 = NdotH * NdotH;
+    const T inv_cos2 = rcp_t(cos2);
+    T dd = exp2_t(((1.f - cos2) * inv_cos2) * m.exp_scale) * (inv_cos2 * inv_cos2) * m.inv_pi_alpha2;
+    dd = if_gt(NdotH, 0.f, dd, zero);
+    // Fresnel (shade.h:22-33), cosI = LdotH
+    const T sinT2 = m.ratio2 * (1.f - LdotH * LdotH);
+    const T cosT = sqrt_t(1.f - sinT2);
+    const T ct = cosT * m.ior, ci = LdotH * m.ior;
+    const T ra = (LdotH - ct) * rcp_t(LdotH + ct);
+    const T rc = (cosT - ci) * rcp_t(cosT + ci);
+    const T ff = if_gt(sinT2, 1.f, one, 0.5f * (ra * ra + rc * rc));
+    // G1(LdotH, LdotH) (shade.h:35-47): DdotH / DdotN = 1 unless LdotH is 0 or NaN
+    const T ll = LdotH * LdotH;
+    const T bl = LdotH * rsq_t(1.f - ll) * m.inv_alpha;
+    const T bl2 = bl * bl;
+    T gl = if_lt(bl, 1.6f, (3.535f * bl + 2.181f * bl2) * rcp_t(1.f + 2.276f * bl + 2.577f * bl2), one);
+    gl = if_gt(ll, 0.f, gl, zero);
+    // G1(VdotH, VdotN): its value depends on the view direction only, the sample decides the sign test
+    const float bv = VdotN * __builtin_amdgcn_rsqf(1.f - VdotN * VdotN) * m.inv_alpha;
+    float gv1 = 1.f;
+    if (bv < 1.6f)
+        gv1 = (3.535f * bv + 2.181f * bv * bv) * __builtin_amdgcn_rcpf(1.f + 2.276f * bv + 2.577f * bv * bv);
+    const T gv = if_gt(VdotH * VdotN, 0.f, zero + gv1, zero);
+    // shade.h:80-90; raytracing.h:48
+    const T sc = (dd * ff) * (gl * gv) * rcp_t((4.f * VdotN) * LdotH);
+    const T wl = LdotN * (20.f * __builtin_amdgcn_rcpf(nl));
+    rx = (lc.x * (m.dif_pi.x + m.spec.x * sc)) * wl;
+    ry = (lc.y * (m.dif_pi.y + m.spec.y * sc)) * wl;
+    rz = (lc.z * (m.dif_pi.z + m.spec.z * sc)) * wl;
+}
+
+// One sample: the weighted BSDF colour (raytracing.h:46-48), IEEE or fast build.
+template <bool IEEE>
+__device__ __forceinline__ f3 shade1(f3 n, f3 v, f3 l, f3 lc, const DMat &m, float nl) {
+    if constexpr (IEEE) {
+        return shade<true>(n, v, l, lc, m, nl);
+    } else {
+        float rx, ry, rz;
+        bsdf_fast<float>(n, v, l.x, l.y, l.z, lc, m, nl, rx, ry, rz);
+        return f3_make(rx, ry, rz);
+    }
+}
+
+// The two samples of a lane.
+template <bool IEEE>
+__device__ __forceinline__ void shade2(f3 n, f3 v, v2f lx, v2f ly, v2f lz, bool want1, bool want2, f3 lc,
+                                       const DMat &m, float nl, f3 &c1, f3 &c2) {
+    if constexpr (IEEE) {
+        if (want1) c1 = shade<true>(n, v, f3_make(lx.x, ly.x, lz.x), lc, m, nl);
+        if (want2) c2 = shade<true>(n, v, f3_make(lx.y, ly.y, lz.y), lc, m, nl);
+    } else {
+        v2f rx, ry, rz;
+        bsdf_fast<v2f>(n, v, lx, ly, lz, lc, m, nl, rx, ry, rz);
+        c1 = f3_make(rx.x, ry.x, rz.x);
+        c2 = f3_make(rx.y, ry.y, rz.y);
     }
 }
 
@@ -504,21 +619,19 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                     p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
                                  L.chain[(64 + lane) * 3 + 2]);
             }
-            f3 l1 = fr.light_pos, l2 = fr.light_pos;
+            f3 l1 = fr.light_pos;
             light_sample(fr.seed, pixel, leaf, k_off + k1, l1.x, l1.y);
-            const f3 sd1 = f3_normalize(f3_sub(l1, p1)); // raytracing.h:43
-            f3 sd2 = sd1;
-            if (second) {
-                light_sample(fr.seed, pixel, leaf, k_off + k2, l2.x, l2.y);
-                sd2 = f3_normalize(f3_sub(l2, p2));
-            }
+            f3 l2 = l1; // (without an upper half the second ray repeats the first)
+            if (second) light_sample(fr.seed, pixel, leaf, k_off + k2, l2.x, l2.y);
             ray2 rr;
             rr.ox = (v2f){p1.x, p2.x};
             rr.oy = (v2f){p1.y, p2.y};
             rr.oz = (v2f){p1.z, p2.z};
-            rr.dx = (v2f){sd1.x, sd2.x};
-            rr.dy = (v2f){sd1.y, sd2.y};
-            rr.dz = (v2f){sd1.z, sd2.z};
+            rr.dx = (v2f){l1.x, l2.x} - rr.ox; // raytracing.h:43: normalize(light - position)
+            rr.dy = (v2f){l1.y, l2.y} - rr.oy;
+            rr.dz = (v2f){l1.z, l2.z} - rr.oz;
+            normalize2(rr.dx, rr.dy, rr.dz);
+            const f3 sd1 = f3_make(rr.dx.x, rr.dy.x, rr.dz.x), sd2 = f3_make(rr.dx.y, rr.dy.y, rr.dz.y);
             // nearest hit of each shadow ray inside the leaf (raytracing.h:45)
             float tmin1 = 0.f, tmin2 = 0.f;
             bool any1 = false, any2 = false;
@@ -561,13 +674,19 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             }
             // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
             // samples of a lane are added in sample order
-            if (live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))))) {
-                acc = f3_add(acc, shade<IEEE>(nrm, view, sd1, fr.light_color, mat, nl)); // raytracing.h:48
-                lit++;
-            }
-            if (live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))))) {
-                acc = f3_add(acc, shade<IEEE>(nrm, view, sd2, fr.light_color, mat, nl));
-                lit++;
+            const bool lit1 = live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
+            const bool lit2 = live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
+            if (lit1 || lit2) {
+                f3 c1, c2;
+                shade2<IEEE>(nrm, view, rr.dx, rr.dy, rr.dz, lit1, lit2, fr.light_color, mat, nl, c1, c2);
+                if (lit1) {
+                    acc = f3_add(acc, c1); // raytracing.h:48
+                    lit++;
+                }
+                if (lit2) {
+                    acc = f3_add(acc, c2);
+                    lit++;
+                }
             }
             wave_lds_sync();
         }
@@ -1010,15 +1129,15 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                                       fr.light_pos.z); // raytracing.h:38-39
                 const f3 l2 = f3_make(250.f + (float)(w2 & 511u), 250.f + (float)((w2 >> 9) & 511u),
                                       fr.light_pos.z);
-                const f3 sd1 = f3_normalize(f3_sub(l1, p1)); // raytracing.h:43
-                const f3 sd2 = f3_normalize(f3_sub(l2, p2));
                 ray2 rr;
                 rr.ox = (v2f){p1.x, p2.x};
                 rr.oy = (v2f){p1.y, p2.y};
                 rr.oz = (v2f){p1.z, p2.z};
-                rr.dx = (v2f){sd1.x, sd2.x};
-                rr.dy = (v2f){sd1.y, sd2.y};
-                rr.dz = (v2f){sd1.z, sd2.z};
+                rr.dx = (v2f){l1.x, l2.x} - rr.ox; // raytracing.h:43: normalize(light - position)
+                rr.dy = (v2f){l1.y, l2.y} - rr.oy;
+                rr.dz = (v2f){l1.z, l2.z} - rr.oz;
+                normalize2(rr.dx, rr.dy, rr.dz);
+                const f3 sd1 = f3_make(rr.dx.x, rr.dy.x, rr.dz.x), sd2 = f3_make(rr.dx.y, rr.dy.y, rr.dz.y);
                 // nearest hit of each shadow ray inside the leaf (raytracing.h:45)
                 float tmin1 = 0.f, tmin2 = 0.f;
                 bool any1 = false, any2 = false;
@@ -1052,13 +1171,19 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                     }
                 }
                 // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
-                if (live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))))) {
-                    acc = f3_add(acc, shade<IEEE>(nrm, view, sd1, fr.light_color, mat, nl)); // raytracing.h:48
-                    lit++;
-                }
-                if (live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))))) {
-                    acc = f3_add(acc, shade<IEEE>(nrm, view, sd2, fr.light_color, mat, nl));
-                    lit++;
+                const bool lit1 = live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
+                const bool lit2 = live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
+                if (lit1 || lit2) {
+                    f3 c1, c2;
+                    shade2<IEEE>(nrm, view, rr.dx, rr.dy, rr.dz, lit1, lit2, fr.light_color, mat, nl, c1, c2);
+                    if (lit1) {
+                        acc = f3_add(acc, c1); // raytracing.h:48
+                        lit++;
+                    }
+                    if (lit2) {
+                        acc = f3_add(acc, c2);
+                        lit++;
+                    }
                 }
                 wave_lds_sync();
             }
@@ -1087,7 +1212,8 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
 __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__restrict__ recs,
                                                         uint32_t rec_cap, float4 *__restrict__ colors,
                                                         DCounters *__restrict__ ctr) {
-    const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
+    const RecMap map = rec_map(ctr, rec_cap); // final: written by the previous kernel
+    const uint32_t n_recs = map.total;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -1099,7 +1225,7 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
             const uint32_t i = base + g * 64 + lane;
             cls[g] = N_CLASSES; // none
             if (i < n_recs) {
-                const DRec *rc = recs + i;
+                const DRec *rc = recs + rec_index(map, i);
                 const uint32_t count = rc->count;
                 bool sorted = false;
                 if (fr.sort_samples && count >= SORT_MIN_LEAF && count <= CAND_MAX) {
@@ -1132,7 +1258,7 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
                 if (cls[g] == c)
                     list[first + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[g] >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask[g], 0u))] =
-                        base + g * 64 + lane;
+                        rec_index(map, base + g * 64 + lane);
                 first += (uint32_t)__popcll(mask[g]);
             }
         }
@@ -1232,14 +1358,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
     const uint32_t wave_id = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
     const uint32_t per_wave = 64 / G;
-    const uint32_t n_recs = min(ctr->n_recs, rec_cap); // final: written by the previous kernel
+    const RecMap map = rec_map(ctr, rec_cap); // final: written by the previous kernel
+    const uint32_t n_recs = map.total;
     const float nl = (float)fr.n_lights;
     const uint32_t k = lane % G;
     uint32_t lit_total = 0;
     unsigned long long tests_total = 0;
     for (uint32_t base = wave_id * per_wave; base < n_recs; base += n_waves * per_wave) {
-        const uint32_t ridx = base + lane / G;
-        const bool live = ridx < n_recs && k < fr.n_lights;
+        const uint32_t flat = base + lane / G;
+        const uint32_t ridx = rec_index(map, min(flat, n_recs - 1));
+        const bool live = flat < n_recs && k < fr.n_lights;
         f3 acc = f3_make(0.f, 0.f, 0.f);
         bool lit = false;
         if (live) {
@@ -1281,7 +1409,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
             tests_total += count;
             if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
                 const DMat mat = mats[rc->mat];
-                acc = f3_add(acc, shade<IEEE>(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat, nl)); // raytracing.h:48
+                acc = f3_add(acc, shade1<IEEE>(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat, nl)); // raytracing.h:48
                 lit = true;
             }
         }
@@ -1292,7 +1420,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
             acc.y += __shfl_xor(acc.y, (int)off);
             acc.z += __shfl_xor(acc.z, (int)off);
         }
-        if (k == 0 && ridx < n_recs) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (k == 0 && flat < n_recs) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
     }
     // statistics: one atomic per wave
 #pragma unroll
@@ -1406,6 +1534,62 @@ __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long 
     atomicAdd(checked, (unsigned long long)nc);
 }
 
+// div2_exact / normalize2 against the plain quotient: pseudo-random denominators over
+// DIV2_DEN_MIN..DIV2_DEN_MAX (log-uniform) and numerators from DIV2_NUM_MIN up to 4 d,
+// of both signs, plus vectors through normalize2 against f3_normalize.
+__global__ void selftest_div_kernel(unsigned long long *bad, unsigned long long *checked) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nb = 0, nc = 0;
+    for (uint32_t it = 0; it < 4096; it++) {
+        uint32_t u[6];
+        for (int k = 0; k < 3; k++) light_sample_u(0x51ED270Bu + k, tid, it & 0xFFFFu, it >> 16, u[2 * k], u[2 * k + 1]);
+        uint32_t w[4];
+        { // four more words: the raw Philox output of another counter
+            uint32_t c0 = tid, c1 = it ^ 0xA5A5A5A5u, key = 0x243F6A88u;
+            for (int r = 0; r < 10; r++) {
+                unsigned long long prod = (unsigned long long)0xD256D193u * c0;
+                uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+                c0 = hi ^ key ^ c1;
+                c1 = lo;
+                key += 0x9E3779B9u;
+            }
+            w[0] = c0; w[1] = c1; w[2] = c0 * 0x9E3779B9u + c1; w[3] = c1 * 0x85EBCA6Bu + c0;
+        }
+        // denominators 2^e * m, e in -39..39; numerators = d * ratio, ratio 2^-f * m', f in 0..20 (or up to 4)
+        v2f dn, nm;
+        for (int k = 0; k < 2; k++) {
+            const int e = (int)(w[k] % 79u) - 39;
+            const float m = __uint_as_float(0x3F800000u | (w[k] >> 9));
+            const float dv = ldexpf(m, e);
+            const int f = (int)(w[k + 2] % 23u) - 2;
+            const float m2 = __uint_as_float(0x3F800000u | (w[k + 2] >> 9));
+            float nv = ldexpf(m2, -f) * dv * 0.999f;
+            if (w[k + 2] & 0x100u) nv = -nv;
+            if (k == 0) { dn.x = dv; nm.x = nv; } else { dn.y = dv; nm.y = nv; }
+        }
+        const bool ok0 = __builtin_fabsf(nm.x) >= DIV2_NUM_MIN && __builtin_fabsf(nm.x) <= 4.f * dn.x;
+        const bool ok1 = __builtin_fabsf(nm.y) >= DIV2_NUM_MIN && __builtin_fabsf(nm.y) <= 4.f * dn.y;
+        const v2f q = div2_exact(nm, recip2_make(dn));
+        if (ok0) { nc++; nb += __float_as_uint(q.x) != __float_as_uint(nm.x / dn.x); }
+        if (ok1) { nc++; nb += __float_as_uint(q.y) != __float_as_uint(nm.y / dn.y); }
+        // two vectors with components -500..500 (some exactly zero), scaled by 2^-12..2^3
+        f3 a = f3_make((float)u[0] - 250.f, (float)u[1] - 250.f, (float)u[2] - 250.f);
+        f3 b = f3_make((float)u[3] - 250.f, (float)u[4] - 250.f, (float)u[5] - 250.f);
+        a = f3_scale(a, ldexpf(1.f + (float)(w[0] & 1023u) * 0x1p-10f, (int)(w[1] & 15u) - 12));
+        b = f3_scale(b, ldexpf(1.f + (float)(w[2] & 1023u) * 0x1p-10f, (int)(w[3] & 15u) - 12));
+        v2f x = (v2f){a.x, b.x}, y = (v2f){a.y, b.y}, z = (v2f){a.z, b.z};
+        normalize2(x, y, z);
+        const f3 na = f3_normalize(a), nb3 = f3_normalize(b);
+        nc += 2;
+        nb += !(__float_as_uint(x.x) == __float_as_uint(na.x) && __float_as_uint(y.x) == __float_as_uint(na.y) &&
+                __float_as_uint(z.x) == __float_as_uint(na.z));
+        nb += !(__float_as_uint(x.y) == __float_as_uint(nb3.x) && __float_as_uint(y.y) == __float_as_uint(nb3.y) &&
+                __float_as_uint(z.y) == __float_as_uint(nb3.z));
+    }
+    if (nb) atomicAdd(bad, (unsigned long long)nb);
+    atomicAdd(checked, (unsigned long long)nc);
+}
+
 // acne_chain_delta against the serial chain on pseudo-random and adversarial inputs
 // (values next to powers of two, increments with few significant bits, both signs).
 __global__ void selftest_chain_kernel(unsigned long long *bad, unsigned long long *checked,
@@ -1477,6 +1661,7 @@ struct rtx_scene {
     rtx_light light{};
     // per-frame work buffers, grown on demand
     DRec *d_recs = nullptr;
+    uint64_t n_hits = 0; // hit records of the last frame
     float4 *d_colors = nullptr;
     uint32_t rec_cap = 0;
     uint32_t *d_first = nullptr;
@@ -1498,13 +1683,13 @@ extern "C" int rtx_device_count(void) {
 
 extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
 
-extern "C" rtx_status rtx_selftest(int device, uint64_t out[5]) {
+extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) {
     if (!out) return fail(RTX_ERR_INVALID, "null argument");
     if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(device));
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 40));
-    hipError_t e = hipMemset(d, 0, 40);
+    HIP_TRY(hipMalloc((void **)&d, 56));
+    hipError_t e = hipMemset(d, 0, 56);
     if (e == hipSuccess) {
         selftest_rcp_kernel<<<4096, 256>>>(d + 1, d);
         e = hipGetLastError();
@@ -1514,12 +1699,17 @@ extern "C" rtx_status rtx_selftest(int device, uint64_t out[5]) {
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) {
+            selftest_div_kernel<<<1024, 256>>>(d + 6, d + 5);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
-    unsigned long long h[5] = {0, 0, 0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpy(h, d, 40, hipMemcpyDeviceToHost);
+    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 56, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
-    for (int k = 0; k < 5; k++) out[k] = h[k];
+    for (int k = 0; k < 7; k++) out[k] = h[k];
     return RTX_OK;
 }
 
@@ -1703,6 +1893,9 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
         o.dif_pi.x = m.diffuse[0] / pi;
         o.dif_pi.y = m.diffuse[1] / pi;
         o.dif_pi.z = m.diffuse[2] / pi;
+        o.exp_scale = -1.44269504088896341f / a2;
+        o.inv_pi_alpha2 = 1.f / pa2;
+        o.inv_alpha = 1.f / m.roughness;
     }
 
     // ---- upload ----
@@ -1825,13 +2018,15 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     // the queue-driven shading kernels get exactly the waves that are resident at once
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
+    const uint32_t trace_blocks = (uint32_t)s->n_cu * TRACE_BLOCKS_PER_CU;
     const uint32_t shade_blocks = (uint32_t)s->n_cu * (p->max_depth ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD);
     const uint32_t merge_blocks = (uint32_t)((npix + MERGE_BLOCK - 1) / MERGE_BLOCK);
 
+    uint64_t n_hits = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
         HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
-        trace_kernel<<<tiles, TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
+        trace_kernel<<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
                                                     s->rec_cap, s->d_first, s->d_ctr);
 #define LAUNCH_FEW(G)                                                                                        \
     do {                                                                                                     \
@@ -1873,16 +2068,23 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (s->h_ctr->n_recs <= s->rec_cap) break;
-        // more hits than the record buffer holds: grow it and render again
+        uint32_t fullest = 0;
+        n_hits = 0;
+        for (int k = 0; k < REC_SHARDS; k++) {
+            fullest = std::max(fullest, s->h_ctr->shard[k].count);
+            n_hits += s->h_ctr->shard[k].count;
+        }
+        if (fullest <= s->rec_cap / REC_SHARDS) break;
+        // a shard got more hits than it holds: grow the record buffer and render again
         if (attempt == 2) return fail(RTX_ERR_HIP, "record buffer overflow persisted");
-        rs = ensure_records(s, (uint64_t)s->h_ctr->n_recs + s->h_ctr->n_recs / 8 + 1024);
+        rs = ensure_records(s, ((uint64_t)fullest + fullest / 8 + 128) * REC_SHARDS);
         if (rs != RTX_OK) return rs;
     }
+    s->n_hits = n_hits;
     if (stats) {
         stats->primary_rays = npix;
-        stats->hits = s->h_ctr->n_recs;
-        stats->shadow_rays = ((uint64_t)s->h_ctr->n_recs + s->h_ctr->bounce_hits) * p->n_lights;
+        stats->hits = n_hits;
+        stats->shadow_rays = (n_hits + s->h_ctr->bounce_hits) * p->n_lights;
         stats->shadow_tests = ((uint64_t)s->h_ctr->leaf_prims + s->h_ctr->bounce_prims) * p->n_lights;
         stats->lit_samples = s->h_ctr->lit;
         stats->shadow_tests_run = s->h_ctr->tests_run;
@@ -1926,13 +2128,19 @@ extern "C" rtx_status rtx_render_hits(rtx_scene *s, const rtx_params *p, rtx_hit
     if (rs != RTX_OK) return rs;
     const uint64_t bytes = (uint64_t)rtx_part_rows(p) * p->width * 3;
     if (rgb_host && bytes) HIP_TRY(hipMemcpy(rgb_host, s->d_rgb, bytes, hipMemcpyDeviceToHost));
-    const uint64_t n = rtx_part_rows(p) ? s->h_ctr->n_recs : 0;
+    const uint64_t n = rtx_part_rows(p) ? s->n_hits : 0;
     *n_hits = n;
     if (!hits || n == 0) return RTX_OK;
     std::vector<DRec> recs(n);
     std::vector<float4> cols(n);
-    HIP_TRY(hipMemcpy(recs.data(), s->d_recs, n * sizeof(DRec), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cols.data(), s->d_colors, n * sizeof(float4), hipMemcpyDeviceToHost));
+    const uint64_t shard_cap = s->rec_cap / REC_SHARDS;
+    for (uint64_t k = 0, at = 0; k < REC_SHARDS; k++) { // the shards of the record array, one after the other
+        const uint64_t m = s->h_ctr->shard[k].count;
+        if (m == 0) continue;
+        HIP_TRY(hipMemcpy(recs.data() + at, s->d_recs + k * shard_cap, m * sizeof(DRec), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cols.data() + at, s->d_colors + k * shard_cap, m * sizeof(float4), hipMemcpyDeviceToHost));
+        at += m;
+    }
     std::vector<uint32_t> order(n);
     for (uint64_t k = 0; k < n; k++) order[k] = (uint32_t)k;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {

@@ -64,7 +64,11 @@ struct __attribute__((aligned(16))) DMat {
     float ratio2;    // (1 / ior) * (1 / ior)            (shade.h:25-26)
     f3 spec;
     f3 dif_pi; // diffuseColor / PI                 (shade.h:70)
-    float pad;
+    // for the fast build of the BSDF
+    float exp_scale;     // -log2(e) / alpha2
+    float inv_pi_alpha2; // 1 / (PI * alpha2)
+    float inv_alpha;     // 1 / roughness
+    float pad[2];
 };
 
 // One (pixel, leaf) hit produced by the trace kernel and consumed by the
@@ -98,16 +102,27 @@ struct DFrame {
     float half_width;
 };
 
+#ifndef REC_SHARDS
+#define REC_SHARDS 8 // parts of the record array, each with its own append counter
+#endif
+
 // Counters of one frame (device memory, zeroed before the trace kernel).
 struct DCounters {
-    uint32_t n_recs;               // records appended (may exceed the capacity)
-    uint32_t pad0;
+    uint32_t pad0[2];
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
     unsigned long long lit;        // light samples that were not occluded
     unsigned long long tests_run;  // shadow-ray primitive tests executed
     unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
     unsigned long long bounce_prims; // sum of the leaf sizes over those
     uint32_t pad1[20];
+    // Hit records appended per shard of the record array (may exceed the shard's capacity).
+    // The trace kernel appends with one returning atomic per wave and leaf; on one word
+    // those would complete at ~50 M/s chip-wide and pace the kernel, so the array is cut
+    // into REC_SHARDS equal parts with a counter each (a block uses shard blockIdx % REC_SHARDS).
+    struct {
+        uint32_t count;
+        uint32_t pad[31];
+    } shard[REC_SHARDS];
     // Work lists of the shading kernel (one per class of record): length, and the work
     // queue over it, sharded eight ways so that the returning atomic on one word (a few
     // tens of millions per second chip-wide) does not pace the kernel: entry e belongs to
@@ -121,6 +136,36 @@ struct DCounters {
         uint32_t pad[31];
     } head[4][8];
 };
+
+// ---- the sharded record array --------------------------------------------------
+// Shard s holds records [s * cap, s * cap + min(count_s, cap)), cap = rec_cap / REC_SHARDS.
+// RecMap enumerates the valid records of all shards as 0 .. total - 1.
+struct RecMap {
+    uint32_t start[REC_SHARDS]; // flat index of the first record of each shard
+    uint32_t total, cap;
+};
+__device__ __forceinline__ RecMap rec_map(const DCounters *ctr, uint32_t rec_cap) {
+    RecMap m;
+    m.cap = rec_cap / REC_SHARDS;
+    uint32_t run = 0;
+#pragma unroll
+    for (int s = 0; s < REC_SHARDS; s++) {
+        m.start[s] = run;
+        run += min(ctr->shard[s].count, m.cap);
+    }
+    m.total = run;
+    return m;
+}
+__device__ __forceinline__ uint32_t rec_index(const RecMap &m, uint32_t flat) {
+    uint32_t s = 0, first = 0;
+#pragma unroll
+    for (int k = 1; k < REC_SHARDS; k++) {
+        const bool ge = flat >= m.start[k];
+        s = ge ? (uint32_t)k : s;
+        first = ge ? m.start[k] : first;
+    }
+    return s * m.cap + (flat - first);
+}
 
 // ---- vec3.h -----------------------------------------------------------------
 __device__ __forceinline__ f3 f3_make(float x, float y, float z) {
@@ -167,12 +212,65 @@ __device__ __forceinline__ bool tri_hit(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float &
     return t > eps;
 }
 
+// a pair of binary32 values: arithmetic on it maps to the packed v_pk_*_f32 instructions
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// n / d for pairs of values that share their denominators, bit-identical to the correctly
+// rounded IEEE quotient: the reciprocal is refined once per denominator (recip2_make) and
+// every numerator then takes one multiply and four fused multiply-adds (div2_exact), the
+// same operations in the same order as the compiler's division expansion when no operand
+// scaling is needed.  That is the case for DIV2_DEN_MIN <= d <= DIV2_DEN_MAX and
+// DIV2_NUM_MIN <= |n| <= 4 d (quotients of vector components by the vector's norm);
+// verified over that range by rtx_selftest().  Elsewhere use the plain division.
+#define DIV2_DEN_MIN 1.0e-12f
+#define DIV2_DEN_MAX 1.0e12f
+#define DIV2_NUM_MIN 1.0e-18f
+struct recip2 {
+    v2f d, r;
+};
+__device__ __forceinline__ recip2 recip2_make(v2f d) {
+    const v2f one = (v2f){1.f, 1.f};
+    const v2f r0 = (v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const v2f e0 = __builtin_elementwise_fma(-d, r0, one);
+    recip2 R;
+    R.d = d;
+    R.r = __builtin_elementwise_fma(e0, r0, r0);
+    return R;
+}
+__device__ __forceinline__ v2f div2_exact(v2f n, const recip2 &R) {
+    const v2f q0 = n * R.r;
+    const v2f e1 = __builtin_elementwise_fma(-R.d, q0, n);
+    const v2f q1 = __builtin_elementwise_fma(e1, R.r, q0);
+    const v2f e2 = __builtin_elementwise_fma(-R.d, q1, n);
+    return __builtin_elementwise_fma(e2, R.r, q1);
+}
+
+// f3_normalize of two vectors at once (x, y, z hold the pairs of components), bit for bit.
+__device__ __forceinline__ void normalize2(v2f &x, v2f &y, v2f &z) {
+    const v2f dd = x * x + y * y + z * z;
+    const v2f len = (v2f){__builtin_sqrtf(dd.x), __builtin_sqrtf(dd.y)};
+    const v2f ax = __builtin_elementwise_abs(x), ay = __builtin_elementwise_abs(y), az = __builtin_elementwise_abs(z);
+    const bool plain = len.x >= DIV2_DEN_MIN && len.x <= DIV2_DEN_MAX && len.y >= DIV2_DEN_MIN &&
+                       len.y <= DIV2_DEN_MAX && ax.x >= DIV2_NUM_MIN && ax.y >= DIV2_NUM_MIN &&
+                       ay.x >= DIV2_NUM_MIN && ay.y >= DIV2_NUM_MIN && az.x >= DIV2_NUM_MIN &&
+                       az.y >= DIV2_NUM_MIN;
+    if (__builtin_expect(__all(plain), 1)) {
+        const recip2 R = recip2_make(len);
+        x = div2_exact(x, R);
+        y = div2_exact(y, R);
+        z = div2_exact(z, R);
+    } else { // a zero or extreme component somewhere in the wave
+        x = x / len;
+        y = y / len;
+        z = z / len;
+    }
+}
+
 // Two rays per lane against one triangle.  Every operation is the same IEEE binary32
 // operation as in tri_hit, done on a pair of values at once so that it maps to the
 // packed v_pk_mul_f32 / v_pk_add_f32 instructions (one issue slot for two results);
 // no operation is fused or reordered.  ok1 / ok2: on entry whether the ray takes
 // part, on return whether it hits (then t holds the distance).
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct ray2 {
     v2f ox, oy, oz; // origins

@@ -290,6 +290,8 @@ def test_arithmetic_shortcuts_are_exact(rtx):
     assert r["rcp_checked"] > 1.4e9 and r["rcp_mismatches"] == 0
     assert r["chain_checked"] > 1e6 and r["chain_mismatches"] == 0
     assert r["chain_declined"] > 1000      # the hard cases exist in the sample and are declined
+    # vec3.h:28-31: the packed division by a shared norm must give the bits of v / |v|
+    assert r["div_checked"] > 1e9 and r["div_mismatches"] == 0, r
 
 
 @pytest.mark.parametrize("cfg,w,h,nl,depth", [("default", 500, 500, 70, 1), ("spheres", 400, 400, 9, 4),
