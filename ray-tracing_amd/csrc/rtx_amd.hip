@@ -177,63 +177,44 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
 // ---- shade.h -------------------------------------------------------------------
 // The BSDF is pure colour arithmetic: nothing it computes feeds a hit, an occlusion or a
 // fold decision other than through the final colour, which is compared with the CPU to
-// 1/255.  Its divisions, square roots and the exponential therefore have two builds:
-// IEEE = true uses the correctly rounded operations (what the rest of the file uses),
-// IEEE = false the hardware's 1-ulp v_rcp / v_sqrt / v_exp, which is ~10x fewer
-// instructions per operation.  Everything that feeds a cancellation (the half vector,
-// the dot products, 1 - cos^2) is computed the same way in both builds, so the two
-// differ by a few ulp of the result, not by an amplified error.
-template <bool IEEE>
-struct Fm {
-    static __device__ __forceinline__ float div(float a, float b) {
-        if constexpr (IEEE) return a / b;
-        else return a * __builtin_amdgcn_rcpf(b);
-    }
-    static __device__ __forceinline__ float sqrt(float x) {
-        if constexpr (IEEE) return __builtin_sqrtf(x);
-        else return __builtin_amdgcn_sqrtf(x);
-    }
-    static __device__ __forceinline__ float exp(float x) {
-        if constexpr (IEEE) return expf(x);
-        else return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-    }
-};
+// 1/255.  It has two builds.  The IEEE build below follows shade.h operation by
+// operation with correctly rounded division, square root and expf (what the rest of the
+// file uses).  The fast build further down uses the hardware's 1-ulp v_rcp / v_rsq /
+// v_sqrt / v_exp, about a tenth of the instructions per operation; everything that feeds
+// a cancellation (the half vector, the dot products, 1 - cos^2) is computed the same way
+// in both builds, so the two differ by a few ulp of the result, not by an amplified error.
 
 // shade.h:7-18
-template <bool IEEE>
 __device__ __forceinline__ float rdm_beckmann(float NdotH, const DMat &m) {
     if (NdotH > 0.f) {
         float cos2 = NdotH * NdotH;
-        float tan2 = Fm<IEEE>::div(1.f - cos2, cos2);
+        float tan2 = (1.f - cos2) / cos2;
         float cos4 = cos2 * cos2;
-        return Fm<IEEE>::div(Fm<IEEE>::exp(Fm<IEEE>::div(-tan2, m.alpha2)), m.pi_alpha2 * cos4);
+        return expf(-tan2 / m.alpha2) / (m.pi_alpha2 * cos4);
     }
     return 0.f;
 }
 
 // shade.h:22-33 with extIOR = 1 (the only call site, shade.h:61); powf(x, 2)
 // is taken as x * x.
-template <bool IEEE>
 __device__ __forceinline__ float rdm_fresnel(float cosI, const DMat &m) {
     float sinT2 = m.ratio2 * (1.f - (cosI * cosI));
     if (sinT2 > 1.f) return 1.f;
-    float cosT = Fm<IEEE>::sqrt(1.f - sinT2);
+    float cosT = __builtin_sqrtf(1.f - sinT2);
     float a = cosI - cosT * m.ior, b = cosI + cosT * m.ior;
     float c = cosT - cosI * m.ior, e = cosT + cosI * m.ior;
-    float Rs = Fm<IEEE>::div(a * a, b * b);
-    float Rp = Fm<IEEE>::div(c * c, e * e);
+    float Rs = (a * a) / (b * b);
+    float Rp = (c * c) / (e * e);
     return 0.5f * (Rs + Rp);
 }
 
 // shade.h:35-47
-template <bool IEEE>
 __device__ __forceinline__ float rdm_g1(float DdotH, float DdotN, float alpha) {
-    float tn = Fm<IEEE>::div(Fm<IEEE>::sqrt(1.f - DdotN * DdotN), DdotN);
-    float b = Fm<IEEE>::div(1.f, alpha * tn);
-    float k = Fm<IEEE>::div(DdotH, DdotN);
+    float tn = __builtin_sqrtf(1.f - DdotN * DdotN) / DdotN;
+    float b = 1.f / (alpha * tn);
+    float k = DdotH / DdotN;
     if (k > 0.f) {
-        if (b < 1.6f)
-            return Fm<IEEE>::div(3.535f * b + 2.181f * b * b, 1.f + 2.276f * b + 2.577f * b * b);
+        if (b < 1.6f) return (3.535f * b + 2.181f * b * b) / (1.f + 2.276f * b + 2.577f * b * b);
         return 1.f;
     }
     return 0.f;
@@ -242,32 +223,19 @@ __device__ __forceinline__ float rdm_g1(float DdotH, float DdotN, float alpha) {
 // shade.h:80-90 with RDM_bsdf, _s and _d inlined, times the per-sample weight
 // 20 / n_lights of raytracing.h:48.  RDM_bsdf receives LdotH in the place of LdotN
 // (shade.h:88); the true LdotN is only the final cosine.
-template <bool IEEE>
-__device__ __forceinline__ f3 shade(f3 n, f3 v, f3 l, f3 lc, const DMat &m, float nl) {
+__device__ __forceinline__ f3 shade_ieee(f3 n, f3 v, f3 l, f3 lc, const DMat &m, float nl) {
     f3 h = f3_normalize(f3_add(v, l));
     float LdotH = f3_dot(l, h);
     float VdotH = f3_dot(v, h);
     float NdotH = f3_dot(n, h);
     float LdotN = f3_dot(l, n);
     float VdotN = f3_dot(v, n);
-    float dd = rdm_beckmann<IEEE>(NdotH, m);
-    float ff = rdm_fresnel<IEEE>(LdotH, m);
-    float gg = rdm_g1<IEEE>(LdotH, LdotH, m.roughness) * rdm_g1<IEEE>(VdotH, VdotN, m.roughness);
-    const f3 num = f3_scale(f3_scale(f3_scale(m.spec, dd), ff), gg);
-    const float den = 4.f * LdotH * VdotN;
-    f3 s, c;
-    if constexpr (IEEE) {
-        s = f3_div(num, den);
-    } else {
-        s = f3_scale(num, __builtin_amdgcn_rcpf(den));
-    }
+    float dd = rdm_beckmann(NdotH, m);
+    float ff = rdm_fresnel(LdotH, m);
+    float gg = rdm_g1(LdotH, LdotH, m.roughness) * rdm_g1(VdotH, VdotN, m.roughness);
+    f3 s = f3_div(f3_scale(f3_scale(f3_scale(m.spec, dd), ff), gg), 4.f * LdotH * VdotN);
     f3 bsdf = f3_add(m.dif_pi, s);
-    c = f3_scale(f3_mul(lc, bsdf), LdotN);
-    if constexpr (IEEE) {
-        return f3_scale(f3_div(c, nl), 20.f);
-    } else {
-        return f3_scale(f3_scale(c, __builtin_amdgcn_rcpf(nl)), 20.f);
-    }
+    return f3_scale(f3_div(f3_scale(f3_mul(lc, bsdf), LdotN), nl), 20.f);
 }
 
 // The fast build of the BSDF, written once for one sample (T = float) and for the two
@@ -351,7 +319,7 @@ __device__ __forceinline__ void bsdf_fast(f3 n, f3 v, T lx, T ly, T lz, f3 lc, c
 template <bool IEEE>
 __device__ __forceinline__ f3 shade1(f3 n, f3 v, f3 l, f3 lc, const DMat &m, float nl) {
     if constexpr (IEEE) {
-        return shade<true>(n, v, l, lc, m, nl);
+        return shade_ieee(n, v, l, lc, m, nl);
     } else {
         float rx, ry, rz;
         bsdf_fast<float>(n, v, l.x, l.y, l.z, lc, m, nl, rx, ry, rz);
@@ -364,8 +332,8 @@ template <bool IEEE>
 __device__ __forceinline__ void shade2(f3 n, f3 v, v2f lx, v2f ly, v2f lz, bool want1, bool want2, f3 lc,
                                        const DMat &m, float nl, f3 &c1, f3 &c2) {
     if constexpr (IEEE) {
-        if (want1) c1 = shade<true>(n, v, f3_make(lx.x, ly.x, lz.x), lc, m, nl);
-        if (want2) c2 = shade<true>(n, v, f3_make(lx.y, ly.y, lz.y), lc, m, nl);
+        if (want1) c1 = shade_ieee(n, v, f3_make(lx.x, ly.x, lz.x), lc, m, nl);
+        if (want2) c2 = shade_ieee(n, v, f3_make(lx.y, ly.y, lz.y), lc, m, nl);
     } else {
         v2f rx, ry, rz;
         bsdf_fast<v2f>(n, v, lx, ly, lz, lc, m, nl, rx, ry, rz);
@@ -409,7 +377,9 @@ __device__ __forceinline__ void shade2(f3 n, f3 v, v2f lx, v2f ly, v2f lz, bool 
 // 3840x2160 / 500 samples: 4 waves (the compiler's own choice, 110 VGPRs) 5.12 ms,
 // 5 waves 4.87 ms, 6 waves 4.86 ms with three times the scratch traffic.  The build
 // with mirror bounces keeps the compiler's 3 waves (158 VGPRs) rather than spill.
+#ifndef SHADE_WAVES_PER_SIMD
 #define SHADE_WAVES_PER_SIMD 5
+#endif
 #define SHADE_WAVES_PER_SIMD_BOUNCE 3
 
 // A wave takes this many records of a queue per atomic.  Returning atomics on one
@@ -715,7 +685,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const f3 n2 = f3_scale(nrm, 2.f); // reflect(), vec3.h:103-106: I - N * 2.f * dot(N, I)
         const f3 rd = f3_normalize(f3_sub(d, f3_scale(n2, f3_dot(nrm, d))));
         const f3 ro = f3_add(pos, f3_scale(rd, fr.acne));
-        const float fres = rdm_fresnel<true>(f3_dot(rd, nrm), mat);
+        const float fres = rdm_fresnel(f3_dot(rd, nrm), mat);
         if (lane == 0) {
             const f3 w = f3_scale(mat.spec, fres);
             L.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);

@@ -13,7 +13,7 @@ for w in buddha bunny dino_spheres multi default; do
 done
 cd /tmp
 echo "rocprofv3 kernel stats"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
 echo "pmc sq"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $O/pmc_sq --output-format csv -- python3 $R/tools/kernel_times.py buddha --frames 2 > $O/pmc_sq.log 2>&1 || exit 1
 echo "pmc fetch"
