@@ -420,7 +420,8 @@ struct ShadeLds {
 
 // Lanes 0..7 each set up one pyramid face: edge (lane & 3) of the light rectangle
 // seen from the first (lane < 4) or last start point, as unit normal (pointing
-// inwards) and offset.  A degenerate face becomes all zeros, which culls nothing.
+// inwards) and offset.  A degenerate face becomes all zeros, which culls nothing; so do
+// all faces when the light plane passes between the two start points.
 __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_first, f3 o_last, float zl) {
     if (lane < 8) {
         const f3 o = (lane < 4) ? o_first : o_last;
@@ -438,7 +439,10 @@ __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_fi
         if (f3_dot(m, dc) < 0.f) m = f3_scale(m, -1.f);
         const float len = __builtin_sqrtf(f3_dot(m, m));
         float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (len > 1e-6f && len < 1e30f) {
+        // Both start points must lie on the same side of the light plane: in between, the
+        // pyramid turns inside out and "outside for both" says nothing about the others.
+        const bool same_side = (zl > o_first.z && zl > o_last.z) || (zl < o_first.z && zl < o_last.z);
+        if (same_side && len > 1e-6f && len < 1e30f) {
             m = f3_scale(m, 1.f / len);
             pl = make_float4(m.x, m.y, m.z, f3_dot(m, o));
         }

@@ -23,14 +23,16 @@ def params_of(capi, fr):
     return p
 
 
-def check_hits(h_gpu, h_cpu):
+def check_hits(h_gpu, h_cpu, color_tol=1e-3):
     assert len(h_gpu) == len(h_cpu)
     for k in ("pixel", "ordinal", "leaf", "prim"):
         assert np.array_equal(h_gpu[k], h_cpu[k]), k
     assert np.array_equal(h_gpu["t"].view(np.uint32), h_cpu["t"].view(np.uint32))
     if len(h_cpu):
         err = np.abs(h_gpu["color"] - h_cpu["color"]) / (np.abs(h_cpu["color"]) + 1e-2)
-        assert err.max() < 1e-3, err.max()
+        # (with the light inside the scene, contributions of both signs cancel in the
+        # per-record sum and the order of the sum shows more: callers pass a wider bound)
+        assert err.max() < color_tol, err.max()
 
 
 def check_rgb(rgb_gpu, rgb_cpu, min_within=0.999):
@@ -109,23 +111,39 @@ def test_other_box_depths_and_seeds(op, capi, built):
         check_rgb(rgb_g, rgb_c)
 
 
-@pytest.mark.parametrize("light_z,acne,nl", [(800.0, 0.5, 100), (100.0, 0.01, 40), (520.0, 0.05, 70),
-                                             (800.0, -0.02, 30), (2000.0, 0.01, 65)])
-def test_light_heights_and_origin_drift(op, capi, scenes, rtx, light_z, acne, nl):
+@pytest.mark.parametrize("cfg,depth,light_z,acne,nl,w,h", [
+    ("default", 8, 800.0, 0.5, 100, 400, 400),
+    ("default", 8, 100.0, 0.01, 40, 400, 400),
+    ("default", 8, 520.0, 0.05, 70, 400, 400),
+    ("default", 8, 800.0, -0.02, 30, 400, 400),
+    ("default", 8, 2000.0, 0.01, 65, 400, 400),
+    # the start points of one record straddle the light plane (the pyramid of its rays
+    # turns inside out on the way): a randomised sweep found blockers dropped here
+    ("default", 6, 420.0, 0.5, 40, 256, 256),
+    ("dino_spheres", 8, 420.0, 0.1, 640, 256, 256),
+    # the same with sorted samples: long drift, light inside the meshes' z range
+    ("multi", 10, 150.0, 0.5, 1030, 200, 120),
+    ("buddha", 10, 420.0, 0.1, 300, 240, 200),
+    ("buddha", 10, 30.0, 0.01, 513, 240, 200),
+])
+def test_light_heights_and_origin_drift(op, capi, scenes, rtx, cfg, depth, light_z, acne, nl, w, h):
     """The screening of leaf triangles against the pyramid of a record's shadow rays
     must never drop a triangle a ray can hit: lights above, below and inside the
     objects' z range, large and negative acne (the start points drift by
-    n_lights * acne along the normal, raytracing.h:40)."""
-    cfg = dict(scenes.CONFIGS["default"])
-    cfg["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
-    b = op.OracleBuilder(8)
-    d = scenes.assemble(b, cfg)
+    n_lights * acne along the normal, raytracing.h:40), with and without sorted samples.
+    The number of lit samples must equal the CPU's, which screens nothing."""
+    c = dict(scenes.CONFIGS[cfg])
+    c["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
+    b = op.OracleBuilder(depth)
+    d = scenes.assemble(b, c)
     sc = rtx.Scene(d)
-    p = capi.default_params(400, 400, nl, 3)
+    p = capi.default_params(w, h, nl, 3)
     p.acne = acne
     rgb_g, hits_g = sc.render_hits(p)
-    rgb_c, _, hits_c, _ = op.render(d, p)
-    check_hits(hits_g, hits_c)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert st_g.lit_samples == st_c.shaded_samples
+    check_hits(hits_g, hits_c, color_tol=3e-3 if acne >= 0.1 else 1e-3)
     check_rgb(rgb_g, rgb_c)
     sc.close()
 
