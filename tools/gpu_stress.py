@@ -32,16 +32,25 @@ bad = 0
 t_start = time.time()
 for case in range(n_cases):
     name = rng.choice(["buddha", "bunny", "multi", "dino_spheres", "default", "spheres"])
-    depth = int(rng.choice([10, 10, 8, 6, 4]))
+    depth = int(rng.choice([10, 10, 8, 6, 4, 0, 12]))
     light_z = float(rng.choice([800.0, 800.0, 1500.0, 420.0, 150.0, 30.0]))
     acne = float(rng.choice([0.01, 0.01, 0.1, 0.001, -0.01, 0.5]))
-    nl = int(rng.choice([129, 150, 256, 300, 500, 513, 640, 1030, 100, 40]))
+    nl = int(rng.choice([129, 150, 256, 300, 500, 513, 640, 1030, 100, 40, 1, 2, 5, 17, 32, 33, 64, 128]))
     w, h = (int(x) for x in rng.choice([[320, 180], [256, 256], [200, 120], [333, 77]]))
     flags = int(rng.choice([0, 0, 0, capi.RTX_FLAG_IEEE_SHADE, capi.RTX_FLAG_NO_SORT]))
     if "RTX_STRESS_FLAGS" in os.environ:  # same cases, one set of flags for all
         flags = int(os.environ["RTX_STRESS_FLAGS"])
-    max_depth = int(rng.choice([0, 0, 0, 0, 1]))
+    max_depth = int(rng.choice([0, 0, 0, 0, 1, 2, 3]))
+    n_parts = int(rng.choice([1, 1, 2, 3]))
+    part = int(rng.integers(0, n_parts))
+    stripe_rows = int(rng.choice([8, 1, 5]))
+    camera = (500.0 + float(rng.choice([0.0, 0.0, -220.0, 180.0])), 500.0 + float(rng.choice([0.0, 0.0, 150.0])),
+              float(rng.choice([3000.0, 3000.0, 1600.0])))
     seed = int(rng.integers(1, 1 << 30))
+    if depth < 6 and name in ("buddha", "multi", "bunny", "dino_spheres"):
+        depth = 6  # (whole meshes in a few leaves take the CPU minutes per frame)
+    print("     case %d: %s depth %d light_z %g acne %g N %d %dx%d flags %d bounces %d part %d/%d stripe %d cam %s seed %d" %
+          (case, name, depth, light_z, acne, nl, w, h, flags, max_depth, part, n_parts, stripe_rows, camera, seed), flush=True)
     cfg = dict(scenes.CONFIGS[name])
     cfg["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
     b = op.OracleBuilder(depth)
@@ -50,6 +59,9 @@ for case in range(n_cases):
     p.acne = acne
     p.max_depth = max_depth
     p.flags = flags
+    p.camera[:] = camera
+    if n_parts > 1:
+        p.stripe_rows, p.n_parts, p.part = stripe_rows, n_parts, part
     t0 = time.time()
     rgb_c, _, hits_c, st_c = op.render(d, p)
     t_cpu = time.time() - t0
@@ -68,9 +80,9 @@ for case in range(n_cases):
     ok = ok_ids and ok_t and ok_lit and within >= 0.999 and rel < 5e-3
     bad += not ok
     print("%s case %2d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s "
-          "(%d vs %d) rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
+          "(%d vs %d) part %d/%d cam %s rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
           ("ok " if ok else "BAD", case, name, depth, light_z, acne, nl, w, h, flags, max_depth, len(hits_c), ok_ids, ok_t,
-           ok_lit, st_g.lit_samples, st_c.shaded_samples, within, float((diff == 0).mean()), rel,
+           ok_lit, st_g.lit_samples, st_c.shaded_samples, part, n_parts, camera, within, float((diff == 0).mean()), rel,
            100.0 * st_g.shadow_tests_run / max(st_g.shadow_tests, 1), t_cpu), flush=True)
 print("%d cases, %d bad, %.0f s" % (n_cases, bad, time.time() - t_start))
 sys.exit(1 if bad else 0)

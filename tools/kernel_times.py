@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times of a workload, frame by frame (GPU box).
-usage: kernel_times.py [workload ...] [--frames N] [--ieee]"""
+usage: kernel_times.py [workload ...] [--frames N] [--ieee] [--parts N (render part 0 of N row-stripe parts)]"""
 import importlib
 import os
 import sys
@@ -13,6 +13,7 @@ host = importlib.import_module("ray-tracing_amd.host_py")
 import bench  # noqa: E402
 
 frames = 8
+parts = 1
 flags = 0
 names = []
 args = sys.argv[1:]
@@ -20,6 +21,8 @@ while args:
     a = args.pop(0)
     if a == "--frames":
         frames = int(args.pop(0))
+    elif a == "--parts":
+        parts = int(args.pop(0))
     elif a == "--ieee":
         flags |= rtx.capi.RTX_FLAG_IEEE_SHADE
     else:
@@ -35,6 +38,8 @@ for name in names or ["bunny", "buddha"]:
     for k in range(frames):
         p = rtx.default_params(w, h, nl, 1)
         p.flags |= flags
+        if parts > 1:
+            p.stripe_rows, p.n_parts, p.part = 8, parts, 0
         t0 = time.perf_counter()
         rgb, st = sc.render(p, timing=True)     # rtx_render: includes the read-back over PCIe
         wall.append((time.perf_counter() - t0) * 1e3)
