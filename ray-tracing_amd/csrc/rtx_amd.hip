@@ -392,14 +392,22 @@ __device__ __forceinline__ void shade2(f3 n, f3 v, v2f lx, v2f ly, v2f lz, bool 
 // Work classes, in the order the shading kernel takes them.  Records with a leaf of
 // SORT_MIN_LEAF..CAND_MAX primitives, more than one pass of light samples and the closed
 // form of all three origin components are shaded with sorted samples (below).
-#define N_CLASSES 4
-#define CLASS_SORTED_HEAVY 0u
-#define CLASS_SORTED_LIGHT 1u
-#define CLASS_PLAIN_HEAVY 2u
-#define CLASS_PLAIN_LIGHT 3u
-#ifndef CLASS_HEAVY_LEAF
-#define CLASS_HEAVY_LEAF 96u  // leaf size from which a record counts as heavy
+#ifndef N_WEIGHTS
+#define N_WEIGHTS 2 // weight groups per kind of record (sorted / plain), by leaf size
 #endif
+#define N_CLASSES (2 * N_WEIGHTS)
+static_assert(N_CLASSES <= WORK_LISTS, "DCounters holds one list per class");
+#define CLASS_SORTED 0u          // classes 0 .. N_WEIGHTS - 1: sorted samples, heaviest first
+#define CLASS_PLAIN N_WEIGHTS    // then the plain records, heaviest first
+#define CLASS_LIGHTEST (N_CLASSES - 1)
+// Weight group of a leaf of `count` primitives, 0 = heaviest.  Two groups (leaves from 96
+// primitives, the rest) measured best: one group leaves long records to the end of the
+// kernel, four cost more in drained-list checks than the finer order gains.
+__device__ __forceinline__ uint32_t weight_group(uint32_t count) {
+    if (N_WEIGHTS == 1) return 0u;
+    if (N_WEIGHTS == 2) return (count >= 96u) ? 0u : 1u;
+    return (count >= 192u) ? 0u : (count >= 96u) ? 1u : (count >= 48u) ? 2u : 3u;
+}
 #define SORT_MIN_LIGHTS 129   // fewer samples are a single pass: nothing to gain
 #ifndef SORT_MIN_LEAF
 #define SORT_MIN_LEAF 12u     // smaller leaves leave too few candidates for the sort to pay
@@ -1208,9 +1216,7 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
                              acne_chain_delta(rc->py, rc->ny * fr.acne, fr.n_lights, dlt) &&
                              acne_chain_delta(rc->pz, rc->nz * fr.acne, fr.n_lights, dlt);
                 }
-                const bool heavy = count >= CLASS_HEAVY_LEAF;
-                cls[g] = sorted ? (heavy ? CLASS_SORTED_HEAVY : CLASS_SORTED_LIGHT)
-                                : (heavy ? CLASS_PLAIN_HEAVY : CLASS_PLAIN_LIGHT);
+                cls[g] = (sorted ? CLASS_SORTED : CLASS_PLAIN) + weight_group(count);
             }
         }
 #pragma unroll
@@ -1257,7 +1263,7 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
     const uint32_t n = ctr->cls[cls].count; // final: written by classify_kernel
     if (n == 0) return;
     const uint32_t *__restrict__ list = work_list(colors, rec_cap, cls);
-    const uint32_t batch = (cls == CLASS_PLAIN_LIGHT) ? QUEUE_BATCH : 1u;
+    const uint32_t batch = (cls == CLASS_LIGHTEST) ? QUEUE_BATCH : 1u;
     uint32_t q = blockIdx.x & 7;
     for (;;) {
         uint32_t k = 0;
@@ -1301,11 +1307,11 @@ void shade_kernel(
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     ShadeTotals tot;
     if constexpr (!BOUNCE) {
-        for (uint32_t cls = CLASS_SORTED_HEAVY; cls <= CLASS_SORTED_LIGHT; cls++)
+        for (uint32_t cls = CLASS_SORTED; cls < CLASS_SORTED + N_WEIGHTS; cls++)
             drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted, lane,
                                           tot);
     }
-    for (uint32_t cls = CLASS_PLAIN_HEAVY; cls <= CLASS_PLAIN_LIGHT; cls++)
+    for (uint32_t cls = CLASS_PLAIN; cls < CLASS_PLAIN + N_WEIGHTS; cls++)
         drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
                                         tot);
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);

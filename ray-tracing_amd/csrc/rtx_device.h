@@ -102,6 +102,7 @@ struct DFrame {
     float half_width;
 };
 
+#define WORK_LISTS 8 // work lists of the shading kernel (classes of hit records)
 #ifndef REC_SHARDS
 #define REC_SHARDS 8 // parts of the record array, each with its own append counter
 #endif
@@ -130,11 +131,11 @@ struct DCounters {
     struct {
         uint32_t count;
         uint32_t pad[31];
-    } cls[4];
+    } cls[WORK_LISTS];
     struct {
         uint32_t next;
         uint32_t pad[31];
-    } head[4][8];
+    } head[WORK_LISTS][8];
 };
 
 // ---- the sharded record array --------------------------------------------------
