@@ -33,7 +33,7 @@
 #endif
 #define SHADE_BLOCK 256
 #define SHADE_WAVES (SHADE_BLOCK / 64)
-#define MERGE_BLOCK 256
+#define MERGE_BLOCK 128
 #define MAX_NEST 24 // deepest box nesting the merge handles (checked at scene creation)
 
 // ---- trace ------------------------------------------------------------------
@@ -1436,13 +1436,29 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_kernel(
     DFrame fr, const DNode *__restrict__ nodes, const DUp *__restrict__ up,
     const DRec *__restrict__ recs, const float4 *__restrict__ colors,
     const uint32_t *__restrict__ first_rec, uint8_t *__restrict__ rgb) {
+    extern __shared__ float merge_stack[]; // (deepest nesting + 1) * 3 * MERGE_BLOCK floats
     const uint32_t local = blockIdx.x * MERGE_BLOCK + threadIdx.x;
     if (local >= fr.rows * fr.width) return;
     float rx = 0.f, ry = 0.f, rz = 0.f;
     uint32_t r = first_rec[local];
-    if (r != RTXD_NONE) {
-        float ax[MAX_NEST], ay[MAX_NEST], az[MAX_NEST];
-        ax[0] = ay[0] = az[0] = 0.f;
+    if (r != RTXD_NONE && recs[r].next == RTXD_NONE) {
+        // One record (the common case): every level from the leaf's up to the top starts
+        // black and takes the colour below it iff that is strictly greater than black in
+        // all three channels; the condition is the same at every level.
+        const float4 c = colors[r];
+        if (all_less(0.f, 0.f, 0.f, c.x, c.y, c.z)) {
+            rx = c.x;
+            ry = c.y;
+            rz = c.z;
+        }
+    } else if (r != RTXD_NONE) {
+        // the colours of the open calls, one per nesting level: LDS, [level][channel][thread]
+#define AX(l) merge_stack[((l) * 3 + 0) * MERGE_BLOCK + threadIdx.x]
+#define AY(l) merge_stack[((l) * 3 + 1) * MERGE_BLOCK + threadIdx.x]
+#define AZ(l) merge_stack[((l) * 3 + 2) * MERGE_BLOCK + threadIdx.x]
+        AX(0) = 0.f;
+        AY(0) = 0.f;
+        AZ(0) = 0.f;
         uint32_t lev = 0, prev = RTXD_NONE;
         while (r != RTXD_NONE) {
             const uint32_t n = recs[r].node;
@@ -1451,37 +1467,44 @@ __global__ __launch_bounds__(MERGE_BLOCK) void merge_kernel(
                 // close the calls that end between the previous leaf and this one
                 uint32_t a = up[prev].parent, l = up[prev].depth;
                 while (a != RTXD_NONE && nodes[a].link <= n) {
-                    if (all_less(ax[l - 1], ay[l - 1], az[l - 1], ax[l], ay[l], az[l])) {
-                        ax[l - 1] = ax[l];
-                        ay[l - 1] = ay[l];
-                        az[l - 1] = az[l];
+                    if (all_less(AX(l - 1), AY(l - 1), AZ(l - 1), AX(l), AY(l), AZ(l))) {
+                        AX(l - 1) = AX(l);
+                        AY(l - 1) = AY(l);
+                        AZ(l - 1) = AZ(l);
                     }
                     l--;
                     a = up[a].parent;
                 }
                 lev = l;
             }
-            for (uint32_t l = lev + 1; l <= depth; l++) ax[l] = ay[l] = az[l] = 0.f;
+            for (uint32_t l = lev + 1; l <= depth; l++) {
+                AX(l) = 0.f;
+                AY(l) = 0.f;
+                AZ(l) = 0.f;
+            }
             const float4 c = colors[r];
-            if (all_less(ax[depth], ay[depth], az[depth], c.x, c.y, c.z)) {
-                ax[depth] = c.x;
-                ay[depth] = c.y;
-                az[depth] = c.z;
+            if (all_less(AX(depth), AY(depth), AZ(depth), c.x, c.y, c.z)) {
+                AX(depth) = c.x;
+                AY(depth) = c.y;
+                AZ(depth) = c.z;
             }
             lev = depth;
             prev = n;
             r = recs[r].next;
         }
         for (uint32_t l = lev; l >= 1; l--) {
-            if (all_less(ax[l - 1], ay[l - 1], az[l - 1], ax[l], ay[l], az[l])) {
-                ax[l - 1] = ax[l];
-                ay[l - 1] = ay[l];
-                az[l - 1] = az[l];
+            if (all_less(AX(l - 1), AY(l - 1), AZ(l - 1), AX(l), AY(l), AZ(l))) {
+                AX(l - 1) = AX(l);
+                AY(l - 1) = AY(l);
+                AZ(l - 1) = AZ(l);
             }
         }
-        rx = ax[0];
-        ry = ay[0];
-        rz = az[0];
+        rx = AX(0);
+        ry = AY(0);
+        rz = AZ(0);
+#undef AX
+#undef AY
+#undef AZ
     }
     uint8_t *out = rgb + (size_t)local * 3;
     out[0] = clamp_color(rx);
@@ -1638,6 +1661,7 @@ struct rtx_scene {
     DPrim *d_prims = nullptr;
     DMat *d_mats = nullptr;
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
+    uint32_t nest_levels = 1; // deepest nesting of a box + 1
     rtx_light light{};
     // per-frame work buffers, grown on demand
     DRec *d_recs = nullptr;
@@ -1803,6 +1827,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     const uint32_t NK = newidx[N];
     std::vector<DNode> nodes(NK);
     std::vector<DUp> ups(NK);
+    uint32_t nest_levels = 1; // deepest nesting of a kept box + 1 (sizes the merge kernel's stack)
     for (uint32_t n = 0; n < N; n++) {
         if (!keep[n]) continue;
         const rtx_node &nd = desc->nodes[n];
@@ -1818,6 +1843,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
         }
         ups[newidx[n]].parent = parent[n] == RTX_NONE ? RTXD_NONE : newidx[parent[n]];
         ups[newidx[n]].depth = depth[n];
+        nest_levels = std::max(nest_levels, depth[n] + 1);
     }
 
     // ---- primitives: ray-independent values precomputed in the reference's
@@ -1892,6 +1918,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     s->device = device;
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     s->n_nodes = NK;
+    s->nest_levels = nest_levels;
     s->n_prims = desc->n_prims;
     s->n_mats = desc->n_materials;
     s->light = desc->light;
@@ -2042,7 +2069,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             else LAUNCH_SHADE(true, false);
         }
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
-        merge_kernel<<<merge_blocks, MERGE_BLOCK, 0, st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
+        merge_kernel<<<merge_blocks, MERGE_BLOCK, (size_t)s->nest_levels * 3 * MERGE_BLOCK * sizeof(float), st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
                                                           s->d_colors, s->d_first, d_rgb);
         if (timing) HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipGetLastError());
