@@ -28,6 +28,12 @@
 // ===========================================================================
 
 #define TRACE_BLOCK 256
+#ifndef TRACE_EARLY_OUT
+#define TRACE_EARLY_OUT true
+#endif
+#ifndef TRACE_STAGE
+#define TRACE_STAGE 64 // primitives of a leaf staged in LDS at a time (40 B each, per wave)
+#endif
 #ifndef TRACE_BLOCKS_PER_CU
 #define TRACE_BLOCKS_PER_CU 8 // resident blocks of trace_kernel per CU (8 waves per SIMD)
 #endif
@@ -35,6 +41,13 @@
 #define SHADE_WAVES (SHADE_BLOCK / 64)
 #define MERGE_BLOCK 128
 #define MAX_NEST 24 // deepest box nesting the merge handles (checked at scene creation)
+
+// LDS written by some lanes of a wave is about to be read by others of the same wave.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- trace ------------------------------------------------------------------
 // One wave = the 64 primary rays of an 8 x 8 pixel tile.  The wave walks the pre-order
@@ -54,6 +67,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     const uint32_t tiles_x = (fr.width + 15) / 16;
     const uint32_t n_tiles = tiles_x * ((fr.rows + 15) / 16);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float stage[TRACE_BLOCK / 64][(TRACE_STAGE / 2) * 20];
+    float *S = stage[wave];
     // the block appends its hit records to one shard of the record array
     const uint32_t shard = blockIdx.x % REC_SHARDS, shard_cap = rec_cap / REC_SHARDS;
     unsigned long long leaf_prims = 0;
@@ -97,22 +112,83 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                 const DPrim *__restrict__ lp = prims + first;
                 float best_t = 0.f;
                 uint32_t best = RTXD_NONE;
-                DPrim pc = lp[0];
-                for (uint32_t k = 0; k < count; k++) {
-                    const DPrim pn = lp[(k + 1 < count) ? k + 1 : k];
-                    if (hit) {
-                        float t;
-                        bool ok;
-                        if ((pc.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                            ok = tri_hit(o, d, pc.a, pc.b, pc.c, t);
-                        else
-                            ok = sph_hit(o, d, pc.a, pc.b.y, t);
-                        if (ok && (best == RTXD_NONE || t < best_t)) {
-                            best_t = t;
-                            best = k;
+                // The leaf goes through LDS, TRACE_STAGE primitives at a time, laid out in
+                // pairs (component c of primitives 2p and 2p + 1 side by side): the lanes fetch
+                // one primitive each and the scan then tests two triangles per step with
+                // packed arithmetic.  A heavy leaf costs a wave ~100 instructions per primitive
+                // one at a time, and the waves over the densest part of a mesh set the
+                // kernel's duration.
+                for (uint32_t base = 0; base < count; base += TRACE_STAGE) {
+                    const uint32_t m = min(count - base, (uint32_t)TRACE_STAGE);
+                    wave_lds_sync(); // the previous batch has been read
+                    if (lane < ((m + 1) & ~1u)) {
+                        float c[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // type 0: no primitive
+                        if (lane < m) {
+                            const DPrim *pp = lp + base + lane;
+                            const float4 *src = reinterpret_cast<const float4 *>(pp);
+                            const float4 q0 = src[0], q1 = src[1]; // a.xyz b.x | b.yz c.xy
+                            c[0] = q0.x, c[1] = q0.y, c[2] = q0.z, c[3] = q0.w;
+                            c[4] = q1.x, c[5] = q1.y, c[6] = q1.z, c[7] = q1.w;
+                            c[8] = pp->c.z;
+                            c[9] = __uint_as_float(pp->type_mat & 0xFFu);
                         }
+                        float *dst = S + (lane >> 1) * 20 + (lane & 1);
+#pragma unroll
+                        for (int k = 0; k < 10; k++) dst[k * 2] = c[k];
                     }
-                    pc = pn;
+                    wave_lds_sync();
+                    const uint32_t n_pairs = (m + 1) >> 1;
+                    const float4 *S4 = reinterpret_cast<const float4 *>(S);
+                    float4 q0 = S4[0], q1 = S4[1], q2 = S4[2], q3 = S4[3], q4 = S4[4];
+                    for (uint32_t pr = 0; pr < n_pairs; pr++) {
+                        const uint32_t pn = (pr + 1 < n_pairs) ? pr + 1 : pr;
+                        const float4 n0 = S4[pn * 5 + 0], n1 = S4[pn * 5 + 1], n2 = S4[pn * 5 + 2],
+                                     n3 = S4[pn * 5 + 3], n4 = S4[pn * 5 + 4];
+                        const uint32_t type_a = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.z));
+                        const uint32_t type_b = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.w));
+                        if (hit) {
+                            const uint32_t ka = base + 2 * pr;
+                            if (type_a == RTX_PRIM_TRIANGLE && type_b == RTX_PRIM_TRIANGLE) {
+                                bool ok_a = true, ok_b = true;
+                                v2f t = (v2f){0.f, 0.f};
+                                tri_hit_pk<float, v2f, TRACE_EARLY_OUT>(o.x, o.y, o.z, d.x, d.y, d.z, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w},
+                                                       (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.x, q2.y},
+                                                       (v2f){q2.z, q2.w}, (v2f){q3.x, q3.y}, (v2f){q3.z, q3.w},
+                                                       (v2f){q4.x, q4.y}, ok_a, ok_b, t);
+                                if (ok_a && (best == RTXD_NONE || t.x < best_t)) {
+                                    best_t = t.x;
+                                    best = ka;
+                                }
+                                if (ok_b && (best == RTXD_NONE || t.y < best_t)) {
+                                    best_t = t.y;
+                                    best = ka + 1;
+                                }
+                            } else { // a sphere, or the odd primitive at the end of the leaf
+                                float t;
+                                bool ok = false;
+                                if (type_a == RTX_PRIM_TRIANGLE)
+                                    ok = tri_hit(o, d, f3_make(q0.x, q0.z, q1.x), f3_make(q1.z, q2.x, q2.z),
+                                                 f3_make(q3.x, q3.z, q4.x), t);
+                                else if (type_a == RTX_PRIM_SPHERE)
+                                    ok = sph_hit(o, d, f3_make(q0.x, q0.z, q1.x), q2.x, t);
+                                if (ok && (best == RTXD_NONE || t < best_t)) {
+                                    best_t = t;
+                                    best = ka;
+                                }
+                                ok = false;
+                                if (type_b == RTX_PRIM_TRIANGLE)
+                                    ok = tri_hit(o, d, f3_make(q0.y, q0.w, q1.y), f3_make(q1.w, q2.y, q2.w),
+                                                 f3_make(q3.y, q3.w, q4.y), t);
+                                else if (type_b == RTX_PRIM_SPHERE)
+                                    ok = sph_hit(o, d, f3_make(q0.y, q0.w, q1.y), q2.y, t);
+                                if (ok && (best == RTXD_NONE || t < best_t)) {
+                                    best_t = t;
+                                    best = ka + 1;
+                                }
+                            }
+                        }
+                        q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4;
+                    }
                 }
                 const bool found = best != RTXD_NONE;
                 const unsigned long long fmask = __ballot(found);
@@ -505,12 +581,6 @@ __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *_
         total += (uint32_t)__popcll(mask);
     }
     return total;
-}
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // One hit record, light samples in index order: one wave, lanes over the samples.

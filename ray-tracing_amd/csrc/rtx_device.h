@@ -296,37 +296,51 @@ __device__ __forceinline__ v2f rcp2_exact(v2f a) {
     return __builtin_elementwise_fma(e2, r1, r2);
 }
 
-__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool &ok1, bool &ok2, v2f &t) {
+// tri_hit on a pair of (ray, triangle) problems at once.  R is the type of the ray's
+// components and P the type of the triangle's: (v2f, float) tests two rays against one
+// triangle, (float, v2f) one ray against two triangles; every operation is the IEEE
+// operation tri_hit performs, on both problems in one packed instruction.  EARLY_OUT =
+// false runs every problem to the end (straight-line code: worth it where the wave has
+// the SIMD to itself and the branches of the early exits cost more than the arithmetic).
+template <typename R, typename P, bool EARLY_OUT = true>
+__device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P v0x, P v0y, P v0z, P e1x, P e1y,
+                                           P e1z, P e2x, P e2y, P e2z, bool &ok1, bool &ok2, v2f &t) {
     const float eps = 0.0000001f;
-    const v2f hx = r.dy * e2.z - r.dz * e2.y;
-    const v2f hy = r.dz * e2.x - r.dx * e2.z;
-    const v2f hz = r.dx * e2.y - r.dy * e2.x;
-    const v2f a = e1.x * hx + e1.y * hy + e1.z * hz;
+    const v2f hx = dy * e2z - dz * e2y;
+    const v2f hy = dz * e2x - dx * e2z;
+    const v2f hz = dx * e2y - dy * e2x;
+    const v2f a = e1x * hx + e1y * hy + e1z * hz;
     ok1 = ok1 && !(a.x > -eps && a.x < eps);
     ok2 = ok2 && !(a.y > -eps && a.y < eps);
-    if (!(ok1 || ok2)) return;
-    // |a| >= 1e-7 for every ray still taking part; only the upper end needs a check
+    if (EARLY_OUT && !(ok1 || ok2)) return;
+    // |a| >= 1e-7 for every problem still open; only the upper end needs a check
     const bool wide = (ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX));
     v2f f;
     if (__builtin_expect(__any(wide), 0))
         f = 1.f / a;
     else
         f = rcp2_exact(a);
-    const v2f sx = r.ox - v0.x, sy = r.oy - v0.y, sz = r.oz - v0.z;
+    const v2f sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
     const v2f u = f * (sx * hx + sy * hy + sz * hz);
     ok1 = ok1 && !(u.x < 0.f || u.x > 1.f);
     ok2 = ok2 && !(u.y < 0.f || u.y > 1.f);
-    if (!(ok1 || ok2)) return;
-    const v2f qx = sy * e1.z - sz * e1.y;
-    const v2f qy = sz * e1.x - sx * e1.z;
-    const v2f qz = sx * e1.y - sy * e1.x;
-    const v2f v = f * (r.dx * qx + r.dy * qy + r.dz * qz);
+    if (EARLY_OUT && !(ok1 || ok2)) return;
+    const v2f qx = sy * e1z - sz * e1y;
+    const v2f qy = sz * e1x - sx * e1z;
+    const v2f qz = sx * e1y - sy * e1x;
+    const v2f v = f * (dx * qx + dy * qy + dz * qz);
     const v2f uv = u + v;
     ok1 = ok1 && !(v.x < 0.f || uv.x > 1.f);
     ok2 = ok2 && !(v.y < 0.f || uv.y > 1.f);
-    t = f * (e2.x * qx + e2.y * qy + e2.z * qz);
+    t = f * (e2x * qx + e2y * qy + e2z * qz);
     ok1 = ok1 && t.x > eps;
     ok2 = ok2 && t.y > eps;
+}
+
+// two rays, one triangle
+__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool &ok1, bool &ok2, v2f &t) {
+    tri_hit_pk<v2f, float>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z,
+                           ok1, ok2, t);
 }
 
 // intersect.h:1-18 (distance only)
