@@ -1,13 +1,16 @@
 // rtx_amd.hip - MI355X (gfx950) render hot path behind the C ABI of include/rtx.h.
 //
-// One frame = three kernels on one stream, no host round trip in between:
-//   trace_kernel  one lane per pixel: primary ray, box walk, nearest hit per
-//                 leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
-//   shade_kernel  one wave per hit record, lanes over the light samples: shadow
-//                 rays against the record's leaf + BSDF (raytracing.h:36-50,
-//                 shade.h) -> one colour per record
-//   merge_kernel  one lane per pixel: per-nesting-level dominance fold of the
-//                 record colours, clamp, truncate (raytracing.h:85-93, :126-130)
+// One frame = four kernels on one stream, no host round trip in between:
+//   trace_kernel     one lane per pixel: primary ray, box walk, nearest hit per
+//                    leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
+//   classify_kernel  one lane per hit record: the record goes to the work list of its
+//                    class (how it will be shaded, how heavy its leaf is)
+//   shade_kernel     one wave per hit record, lanes over the light samples: shadow
+//                    rays against the record's leaf + BSDF (raytracing.h:36-50,
+//                    shade.h) -> one colour per record   (shade_few_kernel: several
+//                    records per wave when there are at most 32 samples)
+//   merge_kernel     one lane per pixel: per-nesting-level dominance fold of the
+//                    record colours, clamp, truncate (raytracing.h:85-93, :126-130)
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (see Makefile).
 #include <hip/hip_runtime.h>
@@ -419,13 +422,14 @@ __device__ __forceinline__ void shade2(f3 n, f3 v, v2f lx, v2f ly, v2f lz, bool 
 }
 
 // ---- shadow + shade ---------------------------------------------------------------
-// One wave per hit record, taken from a device-side queue; lane l of pass q
-// owns light sample 64 q + l.  All lanes of a wave walk the same leaf, so the
-// primitive data is wave-uniform (scalar loads) and only the ray differs per
-// lane.  The shadow-ray origin of sample k is the hit position after k + 1
-// float additions of normal * acne (raytracing.h:40): that chain is inherently
-// serial, so lanes 0..2 (x, y, z) run it 64 steps at a time into LDS and every
-// lane then picks up its own origin.
+// One wave per hit record.  A pass covers 128 light samples, two per lane, carried
+// through the triangle test as packed pairs.  All lanes of a wave walk the same leaf,
+// so the primitive data is wave-uniform (scalar loads) and only the rays differ per
+// lane.  The shadow-ray origin of sample k is the hit position after k + 1 float
+// additions of normal * acne (raytracing.h:40).  Where acne_chain_delta proves that
+// chain equal, bit for bit, to p0 + (k + 1) * delta, every lane computes its origins
+// directly; otherwise lanes 0..2 (x, y, z) run the additions 128 steps at a time into
+// LDS and every lane then picks up its own.
 //
 // Candidate list.  The reference tests every primitive of the leaf for every
 // shadow ray (intersect.h:99-117).  All shadow rays of one record start within
