@@ -33,30 +33,37 @@ def assemble_numpy(parts, height, stripe_rows):
 
 class FrameGather:
     """Gathers the equally padded tiles of all ranks to rank 0 and scatters their rows
-    into one frame tensor there.  Buffers and the row index are allocated once."""
+    into one frame tensor there.  Buffers and the row index are allocated once; the
+    scatter is a single index_copy_ (the padding rows of the tiles go to a spare row
+    behind the frame)."""
 
     def __init__(self, torch, dist, height, width, stripe_rows, world, rank, device):
         self.torch, self.dist = torch, dist
         self.world, self.rank = world, rank
+        self.height = height
         self.pad_rows = max_part_rows(height, stripe_rows, world)
         self.tile = torch.zeros((self.pad_rows, width, 3), dtype=torch.uint8, device=device)
         self.frame = None
         self.bufs = None
         if rank == 0:
-            self.frame = torch.zeros((height, width, 3), dtype=torch.uint8, device=device)
+            self._store = torch.zeros((height + 1, width, 3), dtype=torch.uint8, device=device)
+            self.frame = self._store[:height]
+            index = np.full((world, self.pad_rows), height, np.int64)
+            for k in range(world):
+                rows = rows_of_part(height, stripe_rows, world, k)
+                index[k, :len(rows)] = rows
+            self.index = torch.as_tensor(index.reshape(-1), dtype=torch.long, device=device)
             if world > 1:
-                self.bufs = [torch.zeros_like(self.tile) for _ in range(world)]
-            self.index = [torch.as_tensor(rows_of_part(height, stripe_rows, world, k), dtype=torch.long,
-                                          device=device) for k in range(world)]
+                self._stack = torch.zeros((world, self.pad_rows, width, 3), dtype=torch.uint8, device=device)
+                self.bufs = [self._stack[k] for k in range(world)]
 
     def run(self):
         """Call on every rank after its tile has been rendered into self.tile."""
         if self.world == 1:
-            self.frame.index_copy_(0, self.index[0], self.tile[:len(self.index[0])])
+            self._store.index_copy_(0, self.index, self.tile)
             return self.frame
         self.dist.gather(self.tile, self.bufs if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
-        for k in range(self.world):
-            self.frame.index_copy_(0, self.index[k], self.bufs[k][:len(self.index[k])])
+        self._store.index_copy_(0, self.index, self._stack.view(-1, self._stack.shape[2], 3))
         return self.frame
