@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                                 tri_hit_pk<float, v2f, TRACE_EARLY_OUT>(o.x, o.y, o.z, d.x, d.y, d.z, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w},
                                                        (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.x, q2.y},
                                                        (v2f){q2.z, q2.w}, (v2f){q3.x, q3.y}, (v2f){q3.z, q3.w},
-                                                       (v2f){q4.x, q4.y}, ok_a, ok_b, t);
+                                                       (v2f){q4.x, q4.y}, fr.wide_dets != 0, ok_a, ok_b, t);
                                 if (ok_a && (best == RTXD_NONE || t.x < best_t)) {
                                     best_t = t.x;
                                     best = ka;
@@ -710,7 +710,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                     bool ok1 = live1, ok2 = live2;
                     v2f t = (v2f){0.f, 0.f};
                     if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                        tri_hit2(rr, cur.a, cur.b, cur.c, ok1, ok2, t);
+                        tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
                     } else {
                         float ta = 0.f, tb = 0.f;
                         ok1 = ok1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                         bool ok1 = live1, ok2 = live2;
                         v2f t = (v2f){0.f, 0.f};
                         if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                            tri_hit2(rr, cur.a, cur.b, cur.c, ok1, ok2, t);
+                            tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
                         } else {
                             float ta = 0.f, tb = 0.f;
                             ok1 = ok1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
@@ -1736,6 +1736,7 @@ struct rtx_scene {
     DMat *d_mats = nullptr;
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
     uint32_t nest_levels = 1; // deepest nesting of a box + 1
+    uint32_t wide_dets = 0;   // some triangle's |e1| |e2| is not below the bound of rcp2_exact's range
     rtx_light light{};
     // per-frame work buffers, grown on demand
     DRec *d_recs = nullptr;
@@ -1922,6 +1923,10 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
 
     // ---- primitives: ray-independent values precomputed in the reference's
     // operation order (host x86-64, no contraction) ----
+    // A ray direction has unit length, so |e1 . (d x e2)| <= |e1| |e2| up to rounding: below
+    // DET_BOUND no determinant can reach RCP2_MAX and the intersection kernels skip that check.
+    const double DET_BOUND = 1.0e17;
+    uint32_t wide_dets = 0;
     std::vector<DPrim> prims(desc->n_prims);
     for (uint32_t k = 0; k < desc->n_prims; k++) {
         const rtx_prim &p = desc->prims[k];
@@ -1947,6 +1952,9 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
             o.b.x = e1x, o.b.y = e1y, o.b.z = e1z;
             o.c.x = e2x, o.c.y = e2y, o.c.z = e2z;
             o.n.x = cx / len, o.n.y = cy / len, o.n.z = cz / len;
+            const double l1 = sqrt((double)e1x * e1x + (double)e1y * e1y + (double)e1z * e1z);
+            const double l2 = sqrt((double)e2x * e2x + (double)e2y * e2y + (double)e2z * e2z);
+            if (!(l1 * l2 < DET_BOUND)) wide_dets = 1;
         } else {
             o.a = host_f3(p.g);
             volatile float r2 = p.g[3] * p.g[3];
@@ -1993,6 +2001,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     s->n_nodes = NK;
     s->nest_levels = nest_levels;
+    s->wide_dets = wide_dets;
     s->n_prims = desc->n_prims;
     s->n_mats = desc->n_materials;
     s->light = desc->light;
@@ -2079,6 +2088,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     fr.part = (p->n_parts > 1) ? p->part : 0;
     fr.n_lights = p->n_lights;
     fr.max_depth = p->max_depth;
+    fr.wide_dets = s->wide_dets;
     fr.sort_samples = (p->max_depth == 0 && p->n_lights >= SORT_MIN_LIGHTS && !(p->flags & RTX_FLAG_NO_SORT)) ? 1u : 0u;
     fr.seed = p->seed;
     fr.acne = p->acne;

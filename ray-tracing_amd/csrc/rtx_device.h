@@ -94,6 +94,7 @@ struct DFrame {
     uint32_t n_lights, seed;
     uint32_t max_depth;
     uint32_t sort_samples; // records with large leaves are shaded with sorted light samples
+    uint32_t wide_dets;    // some triangle has edges so long that a determinant may leave rcp2_exact's range
     float acne;
     f3 camera;
     f3 light_pos;
@@ -304,7 +305,8 @@ __device__ __forceinline__ v2f rcp2_exact(v2f a) {
 // the SIMD to itself and the branches of the early exits cost more than the arithmetic).
 template <typename R, typename P, bool EARLY_OUT = true>
 __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P v0x, P v0y, P v0z, P e1x, P e1y,
-                                           P e1z, P e2x, P e2y, P e2z, bool &ok1, bool &ok2, v2f &t) {
+                                           P e1z, P e2x, P e2y, P e2z, bool check_wide, bool &ok1, bool &ok2,
+                                           v2f &t) {
     const float eps = 0.0000001f;
     const v2f hx = dy * e2z - dz * e2y;
     const v2f hy = dz * e2x - dx * e2z;
@@ -313,10 +315,13 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
     ok1 = ok1 && !(a.x > -eps && a.x < eps);
     ok2 = ok2 && !(a.y > -eps && a.y < eps);
     if (EARLY_OUT && !(ok1 || ok2)) return;
-    // |a| >= 1e-7 for every problem still open; only the upper end needs a check
-    const bool wide = (ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX));
+    // |a| >= 1e-7 for every problem still open; the upper end of rcp2_exact's range needs a
+    // check only in a scene with triangle edges so long that |a| <= |e1| |e2| could reach it
+    bool wide = false;
+    if (check_wide)
+        wide = __any((ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX)));
     v2f f;
-    if (__builtin_expect(__any(wide), 0))
+    if (__builtin_expect(wide, 0))
         f = 1.f / a;
     else
         f = rcp2_exact(a);
@@ -338,9 +343,10 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
 }
 
 // two rays, one triangle
-__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool &ok1, bool &ok2, v2f &t) {
+__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool check_wide, bool &ok1, bool &ok2,
+                                         v2f &t) {
     tri_hit_pk<v2f, float>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z,
-                           ok1, ok2, t);
+                           check_wide, ok1, ok2, t);
 }
 
 // intersect.h:1-18 (distance only)

@@ -299,6 +299,35 @@ def test_record_buffer_growth(op, capi, rtx, scenes):
     sc.close()
 
 
+def test_huge_triangles(op, capi, rtx, scenes):
+    """intersect.h:41 `f = 1.f / a` for determinants beyond the range of the packed
+    reciprocal: a floor and a tilted wall with edges of a few 1e9 (|a| up to ~8e18, the
+    squared length of the normal still finite) behind the default scene, hit by primary
+    and by shadow rays."""
+    b = op.OracleBuilder(8)
+    m = b.add_material(scenes.make_material("green"))
+    tris = (capi.Prim * 2)()
+    corners = [((-1e9, -1e9, -100.0), (1e9, -1e9, -100.0), (0.0, 1.5e9, -100.0)),
+               ((-1e9, -1e9, -2e9), (1e9, -1e9, -2e9), (0.0, 1e9, 1.5e9))]
+    for k, tri in enumerate(corners):
+        tris[k].type = capi.RTX_PRIM_TRIANGLE
+        tris[k].g[0:9] = [c for v in tri for c in v]
+        tris[k].material = m
+    b.add_leaf_box(np.float32((-1e10,) * 3), np.float32((1e10,) * 3), tris)
+    d = scenes.assemble(b, "default")
+    sc = rtx.Scene(d)
+    p = capi.default_params(300, 300, 150, 5)
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert len(hits_c) > 300 * 300          # the floor fills the frame behind the meshes
+    assert np.isfinite(hits_c["color"]).all()
+    assert st_g.lit_samples == st_c.shaded_samples
+    check_hits(hits_g, hits_c)
+    check_rgb(rgb_g, rgb_c)
+    sc.close()
+
+
 def test_arithmetic_shortcuts_are_exact(rtx):
     """intersect.h:41 `f = 1.f / a`: the kernel's packed reciprocal must return the bits
     of the correctly rounded quotient for every float it is used for (exhaustive).
