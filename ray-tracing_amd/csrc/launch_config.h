@@ -1,0 +1,25 @@
+// Block sizes and occupancy knobs of the kernels, and the wave-level LDS fence.
+// Part of the single translation unit rtx_amd.hip (included there, in order).
+#pragma once
+
+#define TRACE_BLOCK 256
+#ifndef TRACE_EARLY_OUT
+#define TRACE_EARLY_OUT true
+#endif
+#ifndef TRACE_STAGE
+#define TRACE_STAGE 64 // primitives of a leaf staged in LDS at a time (40 B each, per wave)
+#endif
+#ifndef TRACE_BLOCKS_PER_CU
+#define TRACE_BLOCKS_PER_CU 8 // resident blocks of trace_kernel per CU (8 waves per SIMD)
+#endif
+#define SHADE_BLOCK 256
+#define SHADE_WAVES (SHADE_BLOCK / 64)
+#define MERGE_BLOCK 128
+#define MAX_NEST 24 // deepest box nesting the merge handles (checked at scene creation)
+
+// LDS written by some lanes of a wave is about to be read by others of the same wave.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -1,0 +1,229 @@
+// classify_kernel, shade_kernel (work lists drained by resident waves) and
+// shade_few_kernel (several records per wave for at most 32 samples).
+// Part of the single translation unit rtx_amd.hip (included there, in order).
+#pragma once
+
+// ---- work lists ------------------------------------------------------------------
+// The record goes to the list of its class.  A wave classifies CLASSIFY_PER_LANE x 64
+// records and then reserves their entries with one atomic per class (returning atomics
+// on one address are slow: one per 64 records would cost more than the rest of the kernel).
+#ifndef CLASSIFY_PER_LANE
+#define CLASSIFY_PER_LANE 8
+#endif
+__global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__restrict__ recs,
+                                                        uint32_t rec_cap, float4 *__restrict__ colors,
+                                                        DCounters *__restrict__ ctr) {
+    const RecMap map = rec_map(ctr, rec_cap); // final: written by the previous kernel
+    const uint32_t n_recs = map.total;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per_wave = 64 * CLASSIFY_PER_LANE;
+    for (uint32_t base = wave_id * per_wave; base < n_recs; base += n_waves * per_wave) {
+        uint32_t cls[CLASSIFY_PER_LANE];
+#pragma unroll
+        for (int g = 0; g < CLASSIFY_PER_LANE; g++) {
+            const uint32_t i = base + g * 64 + lane;
+            cls[g] = N_CLASSES; // none
+            if (i < n_recs) {
+                const DRec *rc = recs + rec_index(map, i);
+                const uint32_t count = rc->count;
+                bool sorted = false;
+                if (fr.sort_samples && count >= SORT_MIN_LEAF && count <= CAND_MAX) {
+                    float dlt;
+                    sorted = acne_chain_delta(rc->px, rc->nx * fr.acne, fr.n_lights, dlt) &&
+                             acne_chain_delta(rc->py, rc->ny * fr.acne, fr.n_lights, dlt) &&
+                             acne_chain_delta(rc->pz, rc->nz * fr.acne, fr.n_lights, dlt);
+                }
+                cls[g] = (sorted ? CLASS_SORTED : CLASS_PLAIN) + weight_group(count);
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < N_CLASSES; c++) {
+            unsigned long long mask[CLASSIFY_PER_LANE];
+            uint32_t total = 0;
+#pragma unroll
+            for (int g = 0; g < CLASSIFY_PER_LANE; g++) {
+                mask[g] = __ballot(cls[g] == c);
+                total += (uint32_t)__popcll(mask[g]);
+            }
+            if (total == 0) continue;
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(&ctr->cls[c].count, total);
+            first = __builtin_amdgcn_readfirstlane(first);
+            uint32_t *__restrict__ list = work_list(colors, rec_cap, c);
+#pragma unroll
+            for (int g = 0; g < CLASSIFY_PER_LANE; g++) {
+                if (cls[g] == c)
+                    list[first + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[g] >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mask[g], 0u))] =
+                        rec_index(map, base + g * 64 + lane);
+                first += (uint32_t)__popcll(mask[g]);
+            }
+        }
+    }
+}
+
+// ---- the shading kernel ------------------------------------------------------------
+// classify_kernel has sorted the hit records into N_CLASSES work lists, heaviest class
+// first: records shaded with sorted samples (large leaf, then smaller), then the others
+// (large leaf, then small).  Every wave drains the lists in that order, so that the
+// long records start early and the tail of the kernel is made of short ones.  A list is
+// handed out through eight heads (entry e belongs to head e & 7): a wave starts on the
+// head of its block (blocks b and b + 8 tend to share an XCD, hence an L2) and moves on
+// when it is drained; heads only ever advance, so a wave that has seen all eight
+// drained is done with the list.
+template <bool SORTED, bool BOUNCE, bool IEEE, typename Lds>
+__device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const DPrim *__restrict__ prims,
+                                           const DMat *__restrict__ mats, const DRec *__restrict__ recs,
+                                           uint32_t rec_cap, float4 *__restrict__ colors,
+                                           DCounters *__restrict__ ctr, Lds &L, uint32_t lane,
+                                           ShadeTotals &tot) {
+    const uint32_t n = ctr->cls[cls].count; // final: written by classify_kernel
+    if (n == 0) return;
+    const uint32_t *__restrict__ list = work_list(colors, rec_cap, cls);
+    const uint32_t batch = (cls == CLASS_LIGHTEST) ? QUEUE_BATCH : 1u;
+    uint32_t q = blockIdx.x & 7;
+    for (;;) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&ctr->head[cls][q].next, batch);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k * 8 + q >= n) {
+            // This head is drained.  Look at all eight (plain loads: a failing atomic
+            // per head and wave would add up) and go on with one that is not, if any.
+            uint32_t next = 0xFFFFFFFFu;
+            if (lane < 8)
+                next = __hip_atomic_load(&ctr->head[cls][lane].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t open = (uint32_t)__ballot(lane < 8 && next < n && next * 8 + lane < n);
+            if (open == 0) break; // heads only advance: nothing will ever be left for this wave
+            const uint32_t ahead = open & ~((2u << q) - 1u); // prefer the next one upwards
+            q = (uint32_t)__ffs((int)(ahead ? ahead : open)) - 1u;
+            continue;
+        }
+        for (uint32_t kb = k; kb < k + batch; kb++) {
+            const uint32_t e = kb * 8 + q;
+            if (e >= n) break;
+            const uint32_t ridx = list[e];
+            if constexpr (SORTED)
+                shade_record_sorted<IEEE>(fr, prims, mats, recs, colors, L, lane, ridx, tot);
+            else
+                shade_record<BOUNCE, IEEE>(fr, prims, mats, recs, colors, L, lane, ridx, tot);
+        }
+    }
+}
+
+template <bool BOUNCE, bool IEEE>
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(BOUNCE ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD,
+                                                   BOUNCE ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD)))
+void shade_kernel(
+    DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
+    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
+    DCounters *__restrict__ ctr) {
+    __shared__ union {
+        ShadeLds plain;
+        SortLds sorted;
+    } lds[SHADE_WAVES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ShadeTotals tot;
+    if constexpr (!BOUNCE) {
+        for (uint32_t cls = CLASS_SORTED; cls < CLASS_SORTED + N_WEIGHTS; cls++)
+            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted, lane,
+                                          tot);
+    }
+    for (uint32_t cls = CLASS_PLAIN; cls < CLASS_PLAIN + N_WEIGHTS; cls++)
+        drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
+                                        tot);
+    if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
+    if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
+    if (lane == 0 && tot.bounce_hits) {
+        atomicAdd(&ctr->bounce_hits, (unsigned long long)tot.bounce_hits);
+        atomicAdd(&ctr->bounce_prims, tot.bounce_prims);
+    }
+}
+
+// ---- shadow + shade for few light samples ---------------------------------------
+// With n_lights <= G <= 32 (the reference as committed uses 1) a wave per hit record
+// would leave most lanes idle, so here a wave takes 64 / G records at once: lane
+// l handles sample l % G of record l / G, walks that record's leaf on its own (vector
+// loads, next primitive in flight) and the G lanes of a record are summed with the
+// same butterfly the one-record kernel uses, so both kernels return identical colours.
+// No mirror bounces (max_depth = 0 only).
+template <uint32_t G, bool IEEE>
+__global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
+    DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
+    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
+    DCounters *__restrict__ ctr) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    const uint32_t per_wave = 64 / G;
+    const RecMap map = rec_map(ctr, rec_cap); // final: written by the previous kernel
+    const uint32_t n_recs = map.total;
+    const float nl = (float)fr.n_lights;
+    const uint32_t k = lane % G;
+    uint32_t lit_total = 0;
+    unsigned long long tests_total = 0;
+    for (uint32_t base = wave_id * per_wave; base < n_recs; base += n_waves * per_wave) {
+        const uint32_t flat = base + lane / G;
+        const uint32_t ridx = rec_index(map, min(flat, n_recs - 1));
+        const bool live = flat < n_recs && k < fr.n_lights;
+        f3 acc = f3_make(0.f, 0.f, 0.f);
+        bool lit = false;
+        if (live) {
+            const DRec *rc = recs + ridx;
+            const uint32_t pixel = rc->pixel, count = rc->count;
+            const DPrim *__restrict__ lp = prims + rc->first;
+            const f3 nrm = f3_make(rc->nx, rc->ny, rc->nz);
+            f3 p = f3_make(rc->px, rc->py, rc->pz);
+            f3 o, d;
+            primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+            const f3 step = f3_scale(nrm, fr.acne);
+            for (uint32_t s = 0; s <= k; s++) p = f3_add(p, step); // raytracing.h:40, k + 1 times
+            f3 lpos = fr.light_pos;
+            light_sample(fr.seed, pixel, rc->leaf, k, lpos.x, lpos.y);
+            const f3 sd = f3_normalize(f3_sub(lpos, p)); // raytracing.h:43
+            float tmin = 0.f;
+            bool any = false;
+            f3 a = lp->a, b = lp->b, c = lp->c;
+            uint32_t tm = lp->type_mat;
+            for (uint32_t q = 0; q < count; q++) {
+                const DPrim *pn = lp + ((q + 1 < count) ? q + 1 : q);
+                const f3 na = pn->a, nb = pn->b, nc = pn->c;
+                const uint32_t ntm = pn->type_mat;
+                float t;
+                bool ok;
+                if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                    ok = tri_hit(p, sd, a, b, c, t);
+                else
+                    ok = sph_hit(p, sd, a, b.y, t);
+                if (ok && (!any || t < tmin)) {
+                    tmin = t;
+                    any = true;
+                }
+                a = na;
+                b = nb;
+                c = nc;
+                tm = ntm;
+            }
+            tests_total += count;
+            if (!any || out_of_scene(f3_add(p, f3_scale(sd, tmin)))) {
+                const DMat mat = mats[rc->mat];
+                acc = f3_add(acc, shade1<IEEE>(nrm, f3_scale(d, -1.f), sd, fr.light_color, mat, nl)); // raytracing.h:48
+                lit = true;
+            }
+        }
+        lit_total += (uint32_t)__popcll(__ballot(lit));
+#pragma unroll
+        for (uint32_t off = G / 2; off >= 1; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, (int)off);
+            acc.y += __shfl_xor(acc.y, (int)off);
+            acc.z += __shfl_xor(acc.z, (int)off);
+        }
+        if (k == 0 && flat < n_recs) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    }
+    // statistics: one atomic per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tests_total += __shfl_xor(tests_total, off);
+    if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
+    if (lane == 0 && tests_total) atomicAdd(&ctr->tests_run, tests_total);
+}

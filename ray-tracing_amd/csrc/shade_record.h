@@ -1,0 +1,420 @@
+// Shading of one hit record by one wave: shadow rays against the record's leaf + BSDF,
+// mirror bounces.
+// Part of the single translation unit rtx_amd.hip (included there, in order).
+#pragma once
+
+// ---- shadow + shade ---------------------------------------------------------------
+// One wave per hit record.  A pass covers 128 light samples, two per lane, carried
+// through the triangle test as packed pairs.  All lanes of a wave walk the same leaf,
+// so the primitive data is wave-uniform (scalar loads) and only the rays differ per
+// lane.  The shadow-ray origin of sample k is the hit position after k + 1 float
+// additions of normal * acne (raytracing.h:40).  Where acne_chain_delta proves that
+// chain equal, bit for bit, to p0 + (k + 1) * delta, every lane computes its origins
+// directly; otherwise lanes 0..2 (x, y, z) run the additions 128 steps at a time into
+// LDS and every lane then picks up its own.
+//
+// Candidate list.  The reference tests every primitive of the leaf for every
+// shadow ray (intersect.h:99-117).  All shadow rays of one record start within
+// n_lights * acne of the hit point and aim at the light rectangle
+// [250, 750]^2 x {z_light} (raytracing.h:38-39), so they stay inside the pyramid
+// spanned by the start points and that rectangle (continued beyond it: there is
+// no far limit).  A triangle that lies outside one face of that pyramid, by a
+// margin far above any rounding, fails the exact test for every one of those
+// rays, so leaving it out cannot change a result.  The faces are the planes
+// through a start point and one edge of the rectangle; g(o, v) = det[v - o,
+// La - o, Lb - o] is affine in o and in v, so "all three vertices outside for
+// the first and the last start point" implies "the whole triangle outside for
+// every start point".  Once per record, lanes run that test over the leaf's
+// triangles (one each) and compact the survivors, in order, into LDS; the
+// sample loop then walks only those.  Leaves too large for the list are
+// screened in segments, once per pass.
+#define CAND_MAX 512
+#define CULL_MARGIN 0.5f // world units; start points drift by < 0.1 through rounding
+
+#define PASS_SAMPLES 128 // light samples per pass: two per lane
+
+#define MAX_BOUNCES 8 // deepest mirror recursion (rtx_params::max_depth) the kernel folds
+
+// Register budget of shade_kernel: 5 waves per SIMD (96 VGPRs).  Measured on buddha
+// 3840x2160 / 500 samples: 4 waves (the compiler's own choice, 110 VGPRs) 5.12 ms,
+// 5 waves 4.87 ms, 6 waves 4.86 ms with three times the scratch traffic.  The build
+// with mirror bounces keeps the compiler's 3 waves (158 VGPRs) rather than spill.
+#ifndef SHADE_WAVES_PER_SIMD
+#define SHADE_WAVES_PER_SIMD 5
+#endif
+#define SHADE_WAVES_PER_SIMD_BOUNCE 3
+
+// A wave takes this many records of a queue per atomic.  Returning atomics on one
+// address complete at only a few tens of millions per second, which is the same order
+// as the record rate of a frame with few light samples.
+#ifndef QUEUE_BATCH
+#define QUEUE_BATCH 2u
+#endif
+
+// Work classes, in the order the shading kernel takes them.  Records with a leaf of
+// SORT_MIN_LEAF..CAND_MAX primitives, more than one pass of light samples and the closed
+// form of all three origin components are shaded with sorted samples (below).
+#ifndef N_WEIGHTS
+#define N_WEIGHTS 2 // weight groups per kind of record (sorted / plain), by leaf size
+#endif
+#define N_CLASSES (2 * N_WEIGHTS)
+static_assert(N_CLASSES <= WORK_LISTS, "DCounters holds one list per class");
+#define CLASS_SORTED 0u          // classes 0 .. N_WEIGHTS - 1: sorted samples, heaviest first
+#define CLASS_PLAIN N_WEIGHTS    // then the plain records, heaviest first
+#define CLASS_LIGHTEST (N_CLASSES - 1)
+// Weight group of a leaf of `count` primitives, 0 = heaviest.  Two groups (leaves from 96
+// primitives, the rest) measured best: one group leaves long records to the end of the
+// kernel, four cost more in drained-list checks than the finer order gains.
+__device__ __forceinline__ uint32_t weight_group(uint32_t count) {
+    if (N_WEIGHTS == 1) return 0u;
+    if (N_WEIGHTS == 2) return (count >= 96u) ? 0u : 1u;
+    return (count >= 192u) ? 0u : (count >= 96u) ? 1u : (count >= 48u) ? 2u : 3u;
+}
+#define SORT_MIN_LIGHTS 129   // fewer samples are a single pass: nothing to gain
+#ifndef SORT_MIN_LEAF
+#define SORT_MIN_LEAF 12u     // smaller leaves leave too few candidates for the sort to pay
+#endif
+
+// The work lists (record numbers) lie behind the rec_cap colours, rec_cap entries each.
+__device__ __forceinline__ uint32_t *work_list(float4 *colors, uint32_t rec_cap, uint32_t cls) {
+    return reinterpret_cast<uint32_t *>(colors + rec_cap) + (size_t)cls * rec_cap;
+}
+
+struct ShadeLds {
+    float4 level_sum[MAX_BOUNCES + 2];    // per bounce level: sum of its light samples
+    float4 level_weight[MAX_BOUNCES + 1]; // specular * Fresnel of the level's hit
+    float chain[PASS_SAMPLES * 3];
+    float4 plane[8];
+    uint16_t cand[CAND_MAX];
+};
+
+// Lanes 0..7 each set up one pyramid face: edge (lane & 3) of the light rectangle
+// seen from the first (lane < 4) or last start point, as unit normal (pointing
+// inwards) and offset.  A degenerate face becomes all zeros, which culls nothing; so do
+// all faces when the light plane passes between the two start points.
+__device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_first, f3 o_last, float zl) {
+    if (lane < 8) {
+        const f3 o = (lane < 4) ? o_first : o_last;
+        const uint32_t e = lane & 3;
+        const float xa = (e == 0 || e == 3) ? 250.f : 750.f, ya = (e < 2) ? 250.f : 750.f;
+        const float xb = (e < 2) ? 750.f : 250.f, yb = (e == 1 || e == 2) ? 750.f : 250.f;
+        // corners in order (250,250) (750,250) (750,750) (250,750); edge e = corner e -> e + 1
+        const f3 da = f3_make(xa - o.x, ya - o.y, zl - o.z);
+        const f3 db = f3_make((e == 0 || e == 1) ? 750.f - o.x : 250.f - o.x,
+                              (e == 1 || e == 2) ? 750.f - o.y : 250.f - o.y, zl - o.z);
+        (void)xb;
+        (void)yb;
+        f3 m = f3_cross(da, db);
+        const f3 dc = f3_make(500.f - o.x, 500.f - o.y, zl - o.z);
+        if (f3_dot(m, dc) < 0.f) m = f3_scale(m, -1.f);
+        const float len = __builtin_sqrtf(f3_dot(m, m));
+        float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Both start points must lie on the same side of the light plane: in between, the
+        // pyramid turns inside out and "outside for both" says nothing about the others.
+        const bool same_side = (zl > o_first.z && zl > o_last.z) || (zl < o_first.z && zl < o_last.z);
+        if (same_side && len > 1e-6f && len < 1e30f) {
+            m = f3_scale(m, 1.f / len);
+            pl = make_float4(m.x, m.y, m.z, f3_dot(m, o));
+        }
+        L.plane[lane] = pl;
+    }
+}
+
+// True if triangle (v0, v0 + e1, v0 + e2) may be hit by a shadow ray of the record.
+__device__ __forceinline__ bool may_be_hit(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi) {
+    const f3 v1 = f3_add(v0, e1), v2 = f3_add(v0, e2);
+    bool out = false;
+#pragma unroll 1
+    for (int e = 0; e < 4; e++) {
+        // outside face e as seen from the first AND from the last start point
+        bool both = true;
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const float4 pl = L.plane[e + 4 * w];
+            const float d0 = pl.x * v0.x + pl.y * v0.y + pl.z * v0.z - pl.w;
+            const float d1 = pl.x * v1.x + pl.y * v1.y + pl.z * v1.z - pl.w;
+            const float d2 = pl.x * v2.x + pl.y * v2.y + pl.z * v2.z - pl.w;
+            both &= (d0 < -CULL_MARGIN) & (d1 < -CULL_MARGIN) & (d2 < -CULL_MARGIN);
+        }
+        out |= both;
+    }
+    // all rays move towards the light plane in z
+    out |= (v0.z < z_lo) & (v1.z < z_lo) & (v2.z < z_lo);
+    out |= (v0.z > z_hi) & (v1.z > z_hi) & (v2.z > z_hi);
+    return !out;
+}
+
+// Screens primitives [seg, seg + n) of the leaf (n <= CAND_MAX) and writes the
+// survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.
+__device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
+                                                      uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
+                                                      float z_hi) {
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t t = base + lane;
+        bool keep = false;
+        if (t < n) {
+            const DPrim *p = leaf_prims + seg + t;
+            keep = true;
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) keep = may_be_hit(L, p->a, p->b, p->c, z_lo, z_hi);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            L.cand[pos] = (uint16_t)t;
+        }
+        total += (uint32_t)__popcll(mask);
+    }
+    return total;
+}
+
+// One hit record, light samples in index order: one wave, lanes over the samples.
+// BOUNCE = false is the build for max_depth = 0 (the reference as committed): the
+// mirror-bounce code and its registers are compiled out.  IEEE selects the BSDF build.
+struct ShadeTotals {
+    uint32_t lit = 0, bounce_hits = 0;
+    unsigned long long tests = 0, bounce_prims = 0;
+};
+
+template <bool BOUNCE, bool IEEE>
+__device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__restrict__ prims,
+                                             const DMat *__restrict__ mats, const DRec *__restrict__ recs,
+                                             float4 *__restrict__ colors, ShadeLds &L, uint32_t lane,
+                                             uint32_t ridx, ShadeTotals &tot) {
+        const float nl = (float)fr.n_lights;
+        uint32_t lit_total = 0, bounce_hits = 0;
+        unsigned long long bounce_prims = 0, tests_total = 0;
+        const DRec rc = recs[ridx];
+        const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
+        const DPrim *__restrict__ leaf_prims = prims + rc.first;
+        // state of the current hit: the primary one first, then one per mirror bounce
+        // (raytracing.h:51-61; a bounce is traced inside the same leaf)
+        DMat mat = mats[rc.mat];
+        f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
+        f3 p0 = f3_make(rc.px, rc.py, rc.pz);
+        f3 o, d;
+        primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+        uint32_t depth = 0;
+        for (;;) {
+        const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
+        const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
+        const uint32_t k_off = depth * fr.n_lights; // every bounce draws its own light samples
+        // shadow-ray origins: closed form where provably exact, else the serial chain run
+        // by lanes 0..2 (running origin component and its increment)
+        f3 dlt = f3_make(0.f, 0.f, 0.f);
+        const bool cx = acne_chain_delta(p0.x, step.x, fr.n_lights, dlt.x);
+        const bool cy = acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
+        const bool cz = acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
+        const bool closed = cx && cy && cz;
+        float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
+        const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
+
+        // pyramid of the record's shadow rays
+        const f3 o_last = f3_add(p0, f3_scale(step, nl + 1.f));
+        const float zl = fr.light_pos.z;
+        const float o_zmin = fminf(p0.z, o_last.z), o_zmax = fmaxf(p0.z, o_last.z);
+        const float z_lo = (zl > o_zmax) ? o_zmin - CULL_MARGIN : -3.0e38f;
+        const float z_hi = (zl < o_zmin) ? o_zmax + CULL_MARGIN : 3.0e38f;
+        setup_planes(L, lane, p0, o_last, zl);
+        wave_lds_sync();
+        // a leaf that fits the list is screened once, on the first pass
+        const bool one_segment = count <= CAND_MAX;
+        uint32_t n_cand = 0;
+
+        f3 acc = f3_make(0.f, 0.f, 0.f);
+        uint32_t lit = 0;
+        // Each pass takes 128 samples: lane l owns samples base + l and base + 64 + l and
+        // carries both rays through the triangle tests as packed pairs.
+        for (uint32_t base = 0; base < fr.n_lights; base += PASS_SAMPLES) {
+            const bool second = base + 64 < fr.n_lights; // wave-uniform: any sample in the upper half?
+            const uint32_t k1 = base + lane, k2 = k1 + 64;
+            const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
+            f3 p1, p2;
+            if (closed) {
+                const float s1 = (float)(k1 + 1u), s2 = (float)(k2 + 1u);
+                p1 = f3_make(p0.x + s1 * dlt.x, p0.y + s1 * dlt.y, p0.z + s1 * dlt.z);
+                p2 = f3_make(p0.x + s2 * dlt.x, p0.y + s2 * dlt.y, p0.z + s2 * dlt.z);
+            } else {
+                if (lane < 3) {
+#pragma unroll
+                    for (int s = 0; s < 64; s++) {
+                        run = run + inc;
+                        L.chain[s * 3 + lane] = run;
+                    }
+                    if (second) {
+#pragma unroll
+                        for (int s = 64; s < PASS_SAMPLES; s++) {
+                            run = run + inc;
+                            L.chain[s * 3 + lane] = run;
+                        }
+                    }
+                }
+                wave_lds_sync();
+                p1 = f3_make(L.chain[lane * 3 + 0], L.chain[lane * 3 + 1], L.chain[lane * 3 + 2]);
+                p2 = p1;
+                if (second)
+                    p2 = f3_make(L.chain[(64 + lane) * 3 + 0], L.chain[(64 + lane) * 3 + 1],
+                                 L.chain[(64 + lane) * 3 + 2]);
+            }
+            f3 l1 = fr.light_pos;
+            light_sample(fr.seed, pixel, leaf, k_off + k1, l1.x, l1.y);
+            f3 l2 = l1; // (without an upper half the second ray repeats the first)
+            if (second) light_sample(fr.seed, pixel, leaf, k_off + k2, l2.x, l2.y);
+            ray2 rr;
+            rr.ox = (v2f){p1.x, p2.x};
+            rr.oy = (v2f){p1.y, p2.y};
+            rr.oz = (v2f){p1.z, p2.z};
+            rr.dx = (v2f){l1.x, l2.x} - rr.ox; // raytracing.h:43: normalize(light - position)
+            rr.dy = (v2f){l1.y, l2.y} - rr.oy;
+            rr.dz = (v2f){l1.z, l2.z} - rr.oz;
+            normalize2(rr.dx, rr.dy, rr.dz);
+            const f3 sd1 = f3_make(rr.dx.x, rr.dy.x, rr.dz.x), sd2 = f3_make(rr.dx.y, rr.dy.y, rr.dz.y);
+            // nearest hit of each shadow ray inside the leaf (raytracing.h:45)
+            float tmin1 = 0.f, tmin2 = 0.f;
+            bool any1 = false, any2 = false;
+            for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
+                if (!one_segment || base == 0) {
+                    wave_lds_sync();
+                    n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
+                                              z_lo, z_hi);
+                    wave_lds_sync();
+                }
+                if (n_cand == 0) continue;
+                tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, (uint32_t)PASS_SAMPLES);
+                // walk the list with the next primitive's scalar loads in flight
+                uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)L.cand[0]);
+                DPrim cur = leaf_prims[seg + ci];
+                for (uint32_t c = 0; c < n_cand; c++) {
+                    const uint32_t cn = __builtin_amdgcn_readfirstlane(
+                        (uint32_t)L.cand[(c + 1 < n_cand) ? c + 1 : c]);
+                    const DPrim nxt = leaf_prims[seg + cn];
+                    bool ok1 = live1, ok2 = live2;
+                    v2f t = (v2f){0.f, 0.f};
+                    if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                        tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
+                    } else {
+                        float ta = 0.f, tb = 0.f;
+                        ok1 = ok1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
+                        ok2 = ok2 && sph_hit(p2, sd2, cur.a, cur.b.y, tb);
+                        t = (v2f){ta, tb};
+                    }
+                    if (ok1 && (!any1 || t.x < tmin1)) {
+                        tmin1 = t.x;
+                        any1 = true;
+                    }
+                    if (ok2 && (!any2 || t.y < tmin2)) {
+                        tmin2 = t.y;
+                        any2 = true;
+                    }
+                    cur = nxt;
+                }
+            }
+            // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
+            // samples of a lane are added in sample order
+            const bool lit1 = live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
+            const bool lit2 = live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
+            if (lit1 || lit2) {
+                f3 c1, c2;
+                shade2<IEEE>(nrm, view, rr.dx, rr.dy, rr.dz, lit1, lit2, fr.light_color, mat, nl, c1, c2);
+                if (lit1) {
+                    acc = f3_add(acc, c1); // raytracing.h:48
+                    lit++;
+                }
+                if (lit2) {
+                    acc = f3_add(acc, c2);
+                    lit++;
+                }
+            }
+            wave_lds_sync();
+        }
+        // sum over the lanes (fixed butterfly order, so a frame is reproducible)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+            lit += __shfl_xor(lit, off);
+        }
+        lit_total += lit;
+        if (lane == 0) L.level_sum[depth] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (!BOUNCE || depth >= fr.max_depth) break;
+
+        // ---- mirror bounce (raytracing.h:53-60) ----
+        // the reflected ray starts from the hit position after all the acne steps
+        f3 pos = p0;
+        if (fr.n_lights && closed) {
+            const float sn = (float)fr.n_lights;
+            pos = f3_make(p0.x + sn * dlt.x, p0.y + sn * dlt.y, p0.z + sn * dlt.z);
+        } else if (fr.n_lights) {
+            const uint32_t slot = (fr.n_lights - 1) % PASS_SAMPLES;
+            pos = f3_make(L.chain[slot * 3 + 0], L.chain[slot * 3 + 1], L.chain[slot * 3 + 2]);
+        }
+        const f3 n2 = f3_scale(nrm, 2.f); // reflect(), vec3.h:103-106: I - N * 2.f * dot(N, I)
+        const f3 rd = f3_normalize(f3_sub(d, f3_scale(n2, f3_dot(nrm, d))));
+        const f3 ro = f3_add(pos, f3_scale(rd, fr.acne));
+        const float fres = rdm_fresnel(f3_dot(rd, nrm), mat);
+        if (lane == 0) {
+            const f3 w = f3_scale(mat.spec, fres);
+            L.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);
+        }
+        // nearest hit of the reflected ray in the leaf: lanes over the primitives, then
+        // the smallest distance wins, the earliest primitive on ties (intersect.h:120-128)
+        float bt = 0.f;
+        uint32_t bk = RTXD_NONE;
+        for (uint32_t kk = lane; kk < count; kk += 64) {
+            const DPrim *pp = leaf_prims + kk;
+            float t;
+            bool ok;
+            if ((pp->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                ok = tri_hit(ro, rd, pp->a, pp->b, pp->c, t);
+            else
+                ok = sph_hit(ro, rd, pp->a, pp->b.y, t);
+            if (ok && (bk == RTXD_NONE || t < bt)) {
+                bt = t;
+                bk = kk;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ot = __shfl_xor(bt, off);
+            const uint32_t ok2 = __shfl_xor(bk, off);
+            if (ok2 != RTXD_NONE && (bk == RTXD_NONE || ot < bt || (ot == bt && ok2 < bk))) {
+                bt = ot;
+                bk = ok2;
+            }
+        }
+        bk = __builtin_amdgcn_readfirstlane(bk); // the same in every lane after the reduction
+        bt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bt)));
+        depth++;
+        if (bk == RTXD_NONE) { // the bounce leaves the leaf: it contributes black
+            if (lane == 0) L.level_sum[depth] = make_float4(0.f, 0.f, 0.f, 0.f);
+            break;
+        }
+        bounce_hits++;
+        bounce_prims += count;
+        const DPrim *hp = leaf_prims + bk;
+        const uint32_t htm = hp->type_mat;
+        p0 = f3_add(ro, f3_scale(rd, bt)); // intersect.h:20, :58
+        nrm = ((htm & 0xFFu) == RTX_PRIM_TRIANGLE) ? hp->n : f3_normalize(f3_sub(p0, hp->a));
+        mat = mats[htm >> 8];
+        d = rd;
+        wave_lds_sync();
+        } // bounce loop
+        // colour of the primary hit = its own samples + weight * colour of the bounce, folded
+        // from the deepest level (ret = color + specular * Fresnel * color_reflect, :60)
+        wave_lds_sync();
+        if (lane == 0) {
+            float4 c = L.level_sum[depth];
+            for (uint32_t lv = depth; lv-- > 0;) {
+                const float4 sm = L.level_sum[lv], w = L.level_weight[lv];
+                c = make_float4(sm.x + w.x * c.x, sm.y + w.y * c.y, sm.z + w.z * c.z, 0.f);
+            }
+            colors[ridx] = c;
+        }
+        wave_lds_sync();
+        tot.lit += lit_total;
+        tot.tests += tests_total;
+        tot.bounce_hits += bounce_hits;
+        tot.bounce_prims += bounce_prims;
+}

@@ -1,0 +1,204 @@
+// trace_kernel: primary rays, box walk, nearest hit per leaf -> hit records.
+// Part of the single translation unit rtx_amd.hip (included there, in order).
+#pragma once
+
+// ---- trace ------------------------------------------------------------------
+// One wave = the 64 primary rays of an 8 x 8 pixel tile.  The wave walks the pre-order
+// box array ONCE for all its rays: `n` is wave-uniform, lane l takes part in box n when
+// its own next box n_lane == n.  After an inner box the walk goes to n + 1 if any ray
+// entered it and to its skip link otherwise; a ray that missed an ancestor m waits
+// with n_lane = link(m), and because boxes nest, every waiting ray's link is at or
+// beyond the link of the box just missed, so the uniform walk can never step past a
+// waiting ray and visits exactly the union of the boxes its rays visit, each ray
+// seeing its own boxes in the reference's order (raytracing.h:74-98).  Box and
+// triangle data are therefore wave-uniform: scalar loads (next one already in flight),
+// used as SGPR operands; only the rays live in VGPRs.
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
+    DFrame fr, const DNode *__restrict__ nodes, uint32_t n_nodes, const DPrim *__restrict__ prims,
+    DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
+    DCounters *__restrict__ ctr) {
+    const uint32_t tiles_x = (fr.width + 15) / 16;
+    const uint32_t n_tiles = tiles_x * ((fr.rows + 15) / 16);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) float stage[TRACE_BLOCK / 64][(TRACE_STAGE / 2) * 20];
+    float *S = stage[wave];
+    // the block appends its hit records to one shard of the record array
+    const uint32_t shard = blockIdx.x % REC_SHARDS, shard_cap = rec_cap / REC_SHARDS;
+    unsigned long long leaf_prims = 0;
+    // a block takes the 16 x 16 pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
+    const uint32_t i = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t r = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = i < fr.width && r < fr.rows;
+    if (!__any(valid) || n_nodes == 0) {
+        if (valid) first_rec[r * fr.width + i] = RTXD_NONE;
+        continue;
+    }
+    const uint32_t j = part_row(fr, valid ? r : 0);
+    const uint32_t pixel = j * fr.width + i;
+    const uint32_t local = r * fr.width + i;
+
+    f3 o, d;
+    primary_ray(fr, i, j, o, d);
+    const f3 inv = f3_make(1.f / d.x, 1.f / d.y, 1.f / d.z); // intersect.h:72-74
+
+    uint32_t head = RTXD_NONE, prev = RTXD_NONE, ordinal = 0;
+    uint32_t n_lane = valid ? 0u : n_nodes; // lanes outside the frame never take part
+    uint32_t n = 0;
+    DNode cur = nodes[0];
+    while (n < n_nodes) {
+        const DNode ahead = nodes[(n + 1 < n_nodes) ? n + 1 : n]; // the likely next box
+        const bool mine = n_lane == n;
+        const bool hit = mine && box_hit(o, inv, cur.lb, cur.rt);
+        uint32_t next;
+        if (cur.info == RTXD_NONE) { // inner box
+            next = __any(hit) ? n + 1 : cur.link;
+            if (mine) n_lane = hit ? n + 1 : cur.link;
+        } else {
+            next = n + 1;
+            if (mine) n_lane = n + 1;
+            if (__any(hit)) {
+                // leaf (intersect.h:95-132): every primitive is tested, the smallest
+                // distance wins, the earliest primitive on ties
+                const uint32_t first = cur.link, count = cur.info >> 16, leaf = cur.info & 0xFFFFu;
+                const DPrim *__restrict__ lp = prims + first;
+                float best_t = 0.f;
+                uint32_t best = RTXD_NONE;
+                // The leaf goes through LDS, TRACE_STAGE primitives at a time, laid out in
+                // pairs (component c of primitives 2p and 2p + 1 side by side): the lanes fetch
+                // one primitive each and the scan then tests two triangles per step with
+                // packed arithmetic.  A heavy leaf costs a wave ~100 instructions per primitive
+                // one at a time, and the waves over the densest part of a mesh set the
+                // kernel's duration.
+                for (uint32_t base = 0; base < count; base += TRACE_STAGE) {
+                    const uint32_t m = min(count - base, (uint32_t)TRACE_STAGE);
+                    wave_lds_sync(); // the previous batch has been read
+                    if (lane < ((m + 1) & ~1u)) {
+                        float c[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // type 0: no primitive
+                        if (lane < m) {
+                            const DPrim *pp = lp + base + lane;
+                            const float4 *src = reinterpret_cast<const float4 *>(pp);
+                            const float4 q0 = src[0], q1 = src[1]; // a.xyz b.x | b.yz c.xy
+                            c[0] = q0.x, c[1] = q0.y, c[2] = q0.z, c[3] = q0.w;
+                            c[4] = q1.x, c[5] = q1.y, c[6] = q1.z, c[7] = q1.w;
+                            c[8] = pp->c.z;
+                            c[9] = __uint_as_float(pp->type_mat & 0xFFu);
+                        }
+                        float *dst = S + (lane >> 1) * 20 + (lane & 1);
+#pragma unroll
+                        for (int k = 0; k < 10; k++) dst[k * 2] = c[k];
+                    }
+                    wave_lds_sync();
+                    const uint32_t n_pairs = (m + 1) >> 1;
+                    const float4 *S4 = reinterpret_cast<const float4 *>(S);
+                    float4 q0 = S4[0], q1 = S4[1], q2 = S4[2], q3 = S4[3], q4 = S4[4];
+                    for (uint32_t pr = 0; pr < n_pairs; pr++) {
+                        const uint32_t pn = (pr + 1 < n_pairs) ? pr + 1 : pr;
+                        const float4 n0 = S4[pn * 5 + 0], n1 = S4[pn * 5 + 1], n2 = S4[pn * 5 + 2],
+                                     n3 = S4[pn * 5 + 3], n4 = S4[pn * 5 + 4];
+                        const uint32_t type_a = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.z));
+                        const uint32_t type_b = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.w));
+                        if (hit) {
+                            const uint32_t ka = base + 2 * pr;
+                            if (type_a == RTX_PRIM_TRIANGLE && type_b == RTX_PRIM_TRIANGLE) {
+                                bool ok_a = true, ok_b = true;
+                                v2f t = (v2f){0.f, 0.f};
+                                tri_hit_pk<float, v2f, TRACE_EARLY_OUT>(o.x, o.y, o.z, d.x, d.y, d.z, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w},
+                                                       (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.x, q2.y},
+                                                       (v2f){q2.z, q2.w}, (v2f){q3.x, q3.y}, (v2f){q3.z, q3.w},
+                                                       (v2f){q4.x, q4.y}, fr.wide_dets != 0, ok_a, ok_b, t);
+                                if (ok_a && (best == RTXD_NONE || t.x < best_t)) {
+                                    best_t = t.x;
+                                    best = ka;
+                                }
+                                if (ok_b && (best == RTXD_NONE || t.y < best_t)) {
+                                    best_t = t.y;
+                                    best = ka + 1;
+                                }
+                            } else { // a sphere, or the odd primitive at the end of the leaf
+                                float t;
+                                bool ok = false;
+                                if (type_a == RTX_PRIM_TRIANGLE)
+                                    ok = tri_hit(o, d, f3_make(q0.x, q0.z, q1.x), f3_make(q1.z, q2.x, q2.z),
+                                                 f3_make(q3.x, q3.z, q4.x), t);
+                                else if (type_a == RTX_PRIM_SPHERE)
+                                    ok = sph_hit(o, d, f3_make(q0.x, q0.z, q1.x), q2.x, t);
+                                if (ok && (best == RTXD_NONE || t < best_t)) {
+                                    best_t = t;
+                                    best = ka;
+                                }
+                                ok = false;
+                                if (type_b == RTX_PRIM_TRIANGLE)
+                                    ok = tri_hit(o, d, f3_make(q0.y, q0.w, q1.y), f3_make(q1.w, q2.y, q2.w),
+                                                 f3_make(q3.y, q3.w, q4.y), t);
+                                else if (type_b == RTX_PRIM_SPHERE)
+                                    ok = sph_hit(o, d, f3_make(q0.y, q0.w, q1.y), q2.y, t);
+                                if (ok && (best == RTXD_NONE || t < best_t)) {
+                                    best_t = t;
+                                    best = ka + 1;
+                                }
+                            }
+                        }
+                        q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4;
+                    }
+                }
+                const bool found = best != RTXD_NONE;
+                const unsigned long long fmask = __ballot(found);
+                if (fmask) {
+                    // one atomic per wave reserves the records of all rays that hit
+                    const uint32_t nfound = (uint32_t)__popcll(fmask);
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)fmask) - 1u)
+                        base = atomicAdd(&ctr->shard[shard].count, nfound);
+                    leaf_prims += (unsigned long long)count * nfound;
+                    base = __shfl(base, __ffsll((long long)fmask) - 1);
+                    if (found) {
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0u));
+                        const uint32_t idx = shard * shard_cap + slot;
+                        const DPrim *p = lp + best;
+                        const f3 pos = f3_add(o, f3_scale(d, best_t)); // intersect.h:20, :58
+                        const uint32_t tm = p->type_mat;
+                        f3 nrm;
+                        if ((tm & 0xFFu) == RTX_PRIM_TRIANGLE)
+                            nrm = p->n;
+                        else
+                            nrm = f3_normalize(f3_sub(pos, p->a)); // intersect.h:21
+                        if (slot < shard_cap) {
+                            DRec rc;
+                            rc.pixel = pixel;
+                            rc.node = n;
+                            rc.prim = p->id;
+                            rc.t = best_t;
+                            rc.px = pos.x;
+                            rc.py = pos.y;
+                            rc.pz = pos.z;
+                            rc.mat = tm >> 8;
+                            rc.nx = nrm.x;
+                            rc.ny = nrm.y;
+                            rc.nz = nrm.z;
+                            rc.next = RTXD_NONE;
+                            rc.leaf = leaf;
+                            rc.first = first;
+                            rc.count = count;
+                            rc.ordinal = ordinal;
+                            recs[idx] = rc;
+                            if (prev == RTXD_NONE)
+                                head = idx;
+                            else
+                                recs[prev].next = idx; // only this lane ever touches its own chain
+                            prev = idx;
+                        }
+                        ordinal++;
+                    }
+                }
+            }
+        }
+        cur = (next == n + 1) ? ahead : nodes[(next < n_nodes) ? next : n];
+        n = next;
+    }
+    if (valid) first_rec[local] = head;
+    } // tiles
+    if (lane == 0 && leaf_prims) atomicAdd(&ctr->leaf_prims, leaf_prims);
+}
