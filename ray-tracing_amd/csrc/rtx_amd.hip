@@ -485,7 +485,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
                                                           s->d_colors, s->d_first, d_rgb);
         if (timing) HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sizeof(DCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, offsetof(DCounters, head), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         uint32_t fullest = 0;
         n_hits = 0;

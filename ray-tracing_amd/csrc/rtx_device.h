@@ -109,6 +109,9 @@ struct DFrame {
 #endif
 
 // Counters of one frame (device memory, zeroed before the trace kernel).
+#ifndef QUEUE_HEADS
+#define QUEUE_HEADS 64u // queue heads per work list (a power of two, at most 64: one per lane)
+#endif
 struct DCounters {
     uint32_t pad0[2];
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
@@ -126,9 +129,11 @@ struct DCounters {
         uint32_t pad[31];
     } shard[REC_SHARDS];
     // Work lists of the shading kernel (one per class of record): length, and the work
-    // queue over it, sharded eight ways so that the returning atomic on one word (a few
-    // tens of millions per second chip-wide) does not pace the kernel: entry e belongs to
-    // head e & 7; every word that is hit by atomics sits on a 128-byte line of its own.
+    // queue over it, sharded QUEUE_HEADS ways so that the returning atomic on one word (a
+    // few tens of millions per second chip-wide) does not pace the kernel, least of all
+    // when a list runs dry and every wave finds that out with an atomic: entry e belongs
+    // to head e % QUEUE_HEADS; every word that is hit by atomics sits on a 128-byte line
+    // of its own.
     struct {
         uint32_t count;
         uint32_t pad[31];
@@ -136,7 +141,7 @@ struct DCounters {
     struct {
         uint32_t next;
         uint32_t pad[31];
-    } head[WORK_LISTS][8];
+    } head[WORK_LISTS][QUEUE_HEADS]; // last member: the host reads the counters back up to here
 };
 
 // ---- the sharded record array --------------------------------------------------

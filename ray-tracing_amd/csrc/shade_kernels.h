@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
 // first: records shaded with sorted samples (large leaf, then smaller), then the others
 // (large leaf, then small).  Every wave drains the lists in that order, so that the
 // long records start early and the tail of the kernel is made of short ones.  A list is
-// handed out through eight heads (entry e belongs to head e & 7): a wave starts on the
-// head of its block (blocks b and b + 8 tend to share an XCD, hence an L2) and moves on
-// when it is drained; heads only ever advance, so a wave that has seen all eight
-// drained is done with the list.
+// handed out through QUEUE_HEADS heads (entry e belongs to head e % QUEUE_HEADS): a wave
+// starts on the head of its block (blocks b and b + 8 tend to share an XCD, hence an L2)
+// and moves on when it is drained; heads only ever advance, so a wave that has seen all
+// of them drained is done with the list.
 template <bool SORTED, bool BOUNCE, bool IEEE, typename Lds>
 __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const DPrim *__restrict__ prims,
                                            const DMat *__restrict__ mats, const DRec *__restrict__ recs,
@@ -83,25 +83,29 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
     if (n == 0) return;
     const uint32_t *__restrict__ list = work_list(colors, rec_cap, cls);
     const uint32_t batch = (cls == CLASS_LIGHTEST) ? QUEUE_BATCH : 1u;
-    uint32_t q = blockIdx.x & 7;
+    uint32_t q = blockIdx.x % QUEUE_HEADS, moves = 0;
     for (;;) {
         uint32_t k = 0;
         if (lane == 0) k = atomicAdd(&ctr->head[cls][q].next, batch);
         k = __builtin_amdgcn_readfirstlane(k);
-        if (k * 8 + q >= n) {
-            // This head is drained.  Look at all eight (plain loads: a failing atomic
-            // per head and wave would add up) and go on with one that is not, if any.
+        if (k * QUEUE_HEADS + q >= n) {
+            // This head is drained.  Look at all of them (plain loads: a failing atomic
+            // per head and wave would add up) and go on with one that is not, if any; the
+            // waves spread over the open heads instead of queueing on the same one.
             uint32_t next = 0xFFFFFFFFu;
-            if (lane < 8)
+            if (lane < QUEUE_HEADS)
                 next = __hip_atomic_load(&ctr->head[cls][lane].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t open = (uint32_t)__ballot(lane < 8 && next < n && next * 8 + lane < n);
+            const bool is_open = lane < QUEUE_HEADS && next < n && next * QUEUE_HEADS + lane < n;
+            const unsigned long long open = __ballot(is_open);
             if (open == 0) break; // heads only advance: nothing will ever be left for this wave
-            const uint32_t ahead = open & ~((2u << q) - 1u); // prefer the next one upwards
-            q = (uint32_t)__ffs((int)(ahead ? ahead : open)) - 1u;
+            const uint32_t pick = (blockIdx.x * SHADE_WAVES + (threadIdx.x >> 6) + moves++) % (uint32_t)__popcll(open);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(open >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)open, 0u));
+            q = (uint32_t)__ffsll((long long)__ballot(is_open && rank == pick)) - 1u;
             continue;
         }
         for (uint32_t kb = k; kb < k + batch; kb++) {
-            const uint32_t e = kb * 8 + q;
+            const uint32_t e = kb * QUEUE_HEADS + q;
             if (e >= n) break;
             const uint32_t ridx = list[e];
             if constexpr (SORTED)
