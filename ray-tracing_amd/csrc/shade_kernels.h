@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
 }
 
 // ---- the shading kernel ------------------------------------------------------------
-// classify_kernel has sorted the hit records into N_CLASSES work lists, heaviest class
-// first: records shaded with sorted samples (large leaf, then smaller), then the others
-// (large leaf, then small).  Every wave drains the lists in that order, so that the
+// classify_kernel has sorted the hit records into N_CLASSES work lists: by kind (shaded
+// with sorted samples, or plain) and by leaf size.  Every wave drains the lists in the
+// same order, large leaves first and the most numerous list last, so that the
 // long records start early and the tail of the kernel is made of short ones.  A list is
 // handed out through QUEUE_HEADS heads (entry e belongs to head e % QUEUE_HEADS): a wave
 // starts on the head of its block (blocks b and b + 8 tend to share an XCD, hence an L2)
@@ -82,7 +82,8 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
     const uint32_t n = ctr->cls[cls].count; // final: written by classify_kernel
     if (n == 0) return;
     const uint32_t *__restrict__ list = work_list(colors, rec_cap, cls);
-    const uint32_t batch = (cls == CLASS_LIGHTEST) ? QUEUE_BATCH : 1u;
+    // short records are popped several at a time, unless the list is too short for that
+    const uint32_t batch = (cls == CLASS_LIGHTEST && n >= 8u * gridDim.x * SHADE_WAVES) ? QUEUE_BATCH : 1u;
     uint32_t q = blockIdx.x % QUEUE_HEADS, moves = 0;
     for (;;) {
         uint32_t k = 0;
@@ -129,14 +130,23 @@ void shade_kernel(
     } lds[SHADE_WAVES];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     ShadeTotals tot;
-    if constexpr (!BOUNCE) {
-        for (uint32_t cls = CLASS_SORTED; cls < CLASS_SORTED + N_WEIGHTS; cls++)
-            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted, lane,
-                                          tot);
+    // Long records first, and the most numerous list last: the plain records with a large
+    // leaf (every candidate in every pass), the sorted ones with a large leaf, the plain
+    // ones with a small leaf, then the bulk, sorted with a small leaf.  The kernel ends
+    // when the last record does, and only a list with many more entries than there are
+    // waves keeps every wave busy until then.
+    for (uint32_t step = 0; step < N_CLASSES; step++) {
+        const uint32_t w = step >> 1; // weight group; within it plain before sorted
+        const uint32_t cls = (step & 1u) ? CLASS_SORTED + w : CLASS_PLAIN + w;
+        if (cls < CLASS_PLAIN) {
+            if constexpr (!BOUNCE)
+                drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted,
+                                              lane, tot);
+        } else {
+            drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
+                                            tot);
+        }
     }
-    for (uint32_t cls = CLASS_PLAIN; cls < CLASS_PLAIN + N_WEIGHTS; cls++)
-        drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
-                                        tot);
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
     if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
     if (lane == 0 && tot.bounce_hits) {

@@ -51,7 +51,8 @@
 #define QUEUE_BATCH 2u
 #endif
 
-// Work classes, in the order the shading kernel takes them.  Records with a leaf of
+// Work classes (shade_kernel takes them weight group by weight group, plain before
+// sorted).  Records with a leaf of
 // SORT_MIN_LEAF..CAND_MAX primitives, more than one pass of light samples and the closed
 // form of all three origin components are shaded with sorted samples (below).
 #ifndef N_WEIGHTS
@@ -64,7 +65,7 @@ static_assert(N_CLASSES <= WORK_LISTS, "DCounters holds one list per class");
 #define CLASS_LIGHTEST (N_CLASSES - 1)
 // Weight group of a leaf of `count` primitives, 0 = heaviest.  Two groups (leaves from 96
 // primitives, the rest) measured best: one group leaves long records to the end of the
-// kernel, four cost more in drained-list checks than the finer order gains.
+// kernel, three or four change nothing that can be measured.
 __device__ __forceinline__ uint32_t weight_group(uint32_t count) {
     if (N_WEIGHTS == 1) return 0u;
     if (N_WEIGHTS == 2) return (count >= 96u) ? 0u : 1u;
