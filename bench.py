@@ -118,10 +118,19 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement):
+    # RTX_BENCH_SHARE_GPU=1 puts rank r on GPU r % device_count, RTX_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if os.environ.get("RTX_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     rtx = importlib.import_module("ray-tracing_amd")
     scenes = importlib.import_module("ray-tracing_amd.scenes")
