@@ -6,7 +6,9 @@
 A step is one frame of the workload: the image rows are dealt to the N ranks in stripes
 (one process per GPU, scene replicated), every rank renders its stripes through the C
 ABI (rtx_render_device) into device memory, and the stripes are gathered to rank 0 over
-RCCL.  The scene is uploaded once before the timed region.  Rank 0 prints one JSON line:
+RCCL.  The scene is uploaded once before the timed region.  --inflight frames (default 1)
+are in flight at a time per GPU; every timed frame is complete, gathered and assembled
+before the clock stops.  Rank 0 prints one JSON line:
 
   value     Mrays/s = (primary rays + shadow rays) of the whole frame / frame time, both
             ray counts as counted by the renderer (pixels; hit records x light samples)
@@ -16,6 +18,8 @@ RCCL.  The scene is uploaded once before the timed region.  Rank 0 prints one JS
             sampler) timed on this host's cores on a bounded sample of the same frame
 """
 import argparse
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 import importlib
 import json
 import os
@@ -102,7 +106,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="buddha", choices=sorted(WORKLOADS))
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="frames in flight per GPU (own scene replica, stream and output tile each); with 2 "
+                         "the kernels of consecutive frames overlap: more frames per second, but a kernel's "
+                         "HIP-event duration then includes the time it shares the GPU, so the roofline "
+                         "figures are only meaningful with 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region compare the assembled frames with a full-frame render")
     args = ap.parse_args()
 
     import torch
@@ -137,39 +148,67 @@ def main():
     name, w, h, nl, label = WORKLOADS[args.workload]
 
     builder, desc = build_scene(rtx, scenes, name)
-    scene = rtx.Scene(desc, local_rank)            # uploaded once, resident in HBM
     p = rtx.default_params(w, h, nl, 1)
     p.flags |= rtx.capi.RTX_FLAG_TIMING
     if world > 1:
         p.stripe_rows, p.n_parts, p.part = STRIPE_ROWS, world, rank
     tiles = importlib.import_module("ray-tracing_amd.tiles")
-    gather = tiles.FrameGather(torch, dist, h, w, STRIPE_ROWS, world, rank, dev)
-    tile = gather.tile
-    stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        st = scene.render_device(p, tile.data_ptr(), stream)
-        gather.run()      # RCCL gather to rank 0 + scatter of the stripes into the frame
-        return st
+    # Frames in flight: every slot has its own scene replica (uploaded once, resident in HBM),
+    # HIP stream, output tile and gather buffers.  A worker thread per slot sits in the
+    # blocking render call; the exchange step of the finished frames runs on the main thread
+    # in frame order, so all ranks issue their collectives in the same order.  With more than
+    # one slot a frame's low-occupancy phases (the trace kernel's heaviest tiles, the last
+    # records of the shading kernel, the gather) overlap with the next frame's kernels.
+    n_slots = max(1, args.inflight)
+    replicas = [rtx.Scene(desc, local_rank) for _ in range(n_slots)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)]
+    gathers = [tiles.FrameGather(torch, dist, h, w, STRIPE_ROWS, world, rank, dev) for _ in range(n_slots)]
+    tile_free = [None] * n_slots      # event after which a slot's tile may be overwritten
+    pool = ThreadPoolExecutor(max_workers=n_slots)
+
+    def render(slot):
+        torch.cuda.set_device(local_rank)          # (the current device is per thread)
+        if tile_free[slot] is not None:
+            streams[slot].wait_event(tile_free[slot])
+        return replicas[slot].render_device(p, gathers[slot].tile.data_ptr(), streams[slot].cuda_stream)
+
+    def exchange(slot):
+        gathers[slot].run()   # RCCL gather to rank 0 + scatter of the stripes into the frame
+        tile_free[slot] = torch.cuda.Event()
+        tile_free[slot].record()
+
+    def run_frames(n):
+        """n steps; returns the stats of every frame."""
+        pending, done = deque(), []
+        for f in range(n):
+            slot = f % n_slots
+            pending.append((slot, pool.submit(render, slot)))
+            if len(pending) == n_slots:
+                s_done, fut = pending.popleft()
+                done.append(fut.result())
+                exchange(s_done)
+        while pending:
+            s_done, fut = pending.popleft()
+            done.append(fut.result())
+            exchange(s_done)
+        return done
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_frames(args.warmup)
     fence()
     t0 = time.perf_counter()
-    shade_ms = trace_ms = merge_ms = 0.0
-    st = None
-    for _ in range(args.steps):
-        st = step()
-        trace_ms += st.kernel_ms[0]
-        shade_ms += st.kernel_ms[1]
-        merge_ms += st.kernel_ms[2]
+    frames = run_frames(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    st = frames[-1]
+    trace_ms = sum(f.kernel_ms[0] for f in frames)
+    shade_ms = sum(f.kernel_ms[1] for f in frames)
+    merge_ms = sum(f.kernel_ms[2] for f in frames)
     counts = torch.tensor([elapsed, float(st.primary_rays), float(st.shadow_rays), float(st.shadow_tests),
                            float(st.hits), float(st.lit_samples), float(st.shadow_tests_run)],
                           dtype=torch.float64, device=dev)
@@ -203,7 +242,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "reference mesh geometry (%s), counter-based synthetic light samples, seed 1" % name,
-            "config": {"workload": label, "stripe_rows": STRIPE_ROWS,
+            "config": {"workload": label, "stripe_rows": STRIPE_ROWS, "frames_in_flight": n_slots,
                        "parallelism": "row stripes dealt to %d GPU(s), scene replicated, RCCL gather" % world,
                        "primary_rays": int(primary), "shadow_rays": int(shadow), "hit_records": int(hits)},
             "roofline": {
@@ -239,7 +278,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    scene.close()
+    if args.verify and rank == 0:
+        # the assembled frames of all slots against one full-frame render on this GPU
+        full, _ = replicas[0].render(rtx.default_params(w, h, nl, 1))
+        for k, g in enumerate(gathers[:min(n_slots, args.warmup + args.steps)]):
+            same = bool((g.frame.cpu().numpy() == full).all())
+            print("verify slot %d: assembled frame %s the single-GPU frame" % (k, "equals" if same else "DIFFERS FROM"),
+                  file=sys.stderr, flush=True)
+            if not same:
+                raise SystemExit(1)
+    pool.shutdown()
+    for scene in replicas:
+        scene.close()
 
 
 if __name__ == "__main__":
