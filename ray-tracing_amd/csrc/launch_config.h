@@ -9,6 +9,13 @@
 #ifndef TRACE_STAGE
 #define TRACE_STAGE 64 // primitives of a leaf staged in LDS at a time (40 B each, per wave)
 #endif
+// trace_kernel<SLICES>: lanes per primary ray (they share the scan of a leaf).  Two halve
+// the longest chain of dependent work in the kernel (the leaves over the densest part of a
+// mesh) and double the number of waves that walk the boxes: a gain where leaves are large,
+// a loss where they are small.  rtx_scene_create picks by the mean leaf size.
+#ifndef TRACE_SLICE_MIN_LEAF
+#define TRACE_SLICE_MIN_LEAF 20u
+#endif
 #ifndef TRACE_BLOCKS_PER_CU
 #define TRACE_BLOCKS_PER_CU 8 // resident blocks of trace_kernel per CU (8 waves per SIMD)
 #endif

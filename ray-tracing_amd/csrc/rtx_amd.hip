@@ -65,6 +65,7 @@ struct rtx_scene {
     uint32_t n_nodes = 0, n_prims = 0, n_mats = 0;
     uint32_t nest_levels = 1; // deepest nesting of a box + 1
     uint32_t wide_dets = 0;   // some triangle's |e1| |e2| is not below the bound of rcp2_exact's range
+    uint32_t trace_slices = 1; // lanes per primary ray in trace_kernel (1 or 2)
     rtx_light light{};
     // per-frame work buffers, grown on demand
     DRec *d_recs = nullptr;
@@ -330,6 +331,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     s->n_nodes = NK;
     s->nest_levels = nest_levels;
     s->wide_dets = wide_dets;
+    s->trace_slices = (desc->n_leaves && desc->n_prims / desc->n_leaves >= TRACE_SLICE_MIN_LEAF) ? 2u : 1u;
     s->n_prims = desc->n_prims;
     s->n_mats = desc->n_materials;
     s->light = desc->light;
@@ -433,7 +435,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (rs != RTX_OK) return rs;
     }
     const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
-    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + 15) / 16);
+    const uint32_t tile_h = 16 / s->trace_slices;
+    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + tile_h - 1) / tile_h);
     // the queue-driven shading kernels get exactly the waves that are resident at once
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
@@ -445,8 +448,12 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     for (int attempt = 0; attempt < 3; attempt++) {
         HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
-        trace_kernel<<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs,
-                                                    s->rec_cap, s->d_first, s->d_ctr);
+        if (s->trace_slices == 2)
+            trace_kernel<2><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(
+                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_ctr);
+        else
+            trace_kernel<1><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(
+                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_ctr);
 #define LAUNCH_FEW(G)                                                                                        \
     do {                                                                                                     \
         if (ieee)                                                                                            \

@@ -3,7 +3,7 @@
 #pragma once
 
 // ---- trace ------------------------------------------------------------------
-// One wave = the 64 primary rays of an 8 x 8 pixel tile.  The wave walks the pre-order
+// One wave = the primary rays of an 8 x 8 pixel tile (or a part of one, see TRACE_SLICES).  The wave walks the pre-order
 // box array ONCE for all its rays: `n` is wave-uniform, lane l takes part in box n when
 // its own next box n_lane == n.  After an inner box the walk goes to n + 1 if any ray
 // entered it and to its skip link otherwise; a ray that missed an ancestor m waits
@@ -13,13 +13,18 @@
 // seeing its own boxes in the reference's order (raytracing.h:74-98).  Box and
 // triangle data are therefore wave-uniform: scalar loads (next one already in flight),
 // used as SGPR operands; only the rays live in VGPRs.
+template <uint32_t TRACE_SLICES>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     DFrame fr, const DNode *__restrict__ nodes, uint32_t n_nodes, const DPrim *__restrict__ prims,
     DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
     DCounters *__restrict__ ctr) {
+    // A wave takes 8 x (8 / TRACE_SLICES) pixels; lane l carries ray l % RAYS and, in a leaf,
+    // tests every TRACE_SLICES-th pair of primitives, starting with pair l / RAYS.
+    constexpr uint32_t RAYS = 64 / TRACE_SLICES, TILE_H = 16 / TRACE_SLICES;
     const uint32_t tiles_x = (fr.width + 15) / 16;
-    const uint32_t n_tiles = tiles_x * ((fr.rows + 15) / 16);
+    const uint32_t n_tiles = tiles_x * ((fr.rows + TILE_H - 1) / TILE_H);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ray = lane % RAYS, slice = lane / RAYS;
     __shared__ __attribute__((aligned(16))) float stage[TRACE_BLOCK / 64][(TRACE_STAGE / 2) * 20];
     float *S = stage[wave];
     // the block appends its hit records to one shard of the record array
@@ -28,11 +33,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     // a block takes the 16 x 16 pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
-    const uint32_t i = bx * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t r = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t i = bx * 16 + (wave & 1) * 8 + (ray & 7);
+    const uint32_t r = by * TILE_H + (wave >> 1) * (TILE_H / 2) + (ray >> 3);
     const bool valid = i < fr.width && r < fr.rows;
     if (!__any(valid) || n_nodes == 0) {
-        if (valid) first_rec[r * fr.width + i] = RTXD_NONE;
+        if (valid && slice == 0) first_rec[r * fr.width + i] = RTXD_NONE;
         continue;
     }
     const uint32_t j = part_row(fr, valid ? r : 0);
@@ -92,14 +97,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                     wave_lds_sync();
                     const uint32_t n_pairs = (m + 1) >> 1;
                     const float4 *S4 = reinterpret_cast<const float4 *>(S);
-                    float4 q0 = S4[0], q1 = S4[1], q2 = S4[2], q3 = S4[3], q4 = S4[4];
-                    for (uint32_t pr = 0; pr < n_pairs; pr++) {
-                        const uint32_t pn = (pr + 1 < n_pairs) ? pr + 1 : pr;
+                    uint32_t pr = min(slice, n_pairs - 1);
+                    float4 q0 = S4[pr * 5 + 0], q1 = S4[pr * 5 + 1], q2 = S4[pr * 5 + 2], q3 = S4[pr * 5 + 3],
+                           q4 = S4[pr * 5 + 4];
+                    for (uint32_t step = 0; step < n_pairs; step += TRACE_SLICES) {
+                        const bool mine_pair = step + slice < n_pairs;
+                        pr = min(step + slice, n_pairs - 1);
+                        const uint32_t pn = min(pr + TRACE_SLICES, n_pairs - 1);
                         const float4 n0 = S4[pn * 5 + 0], n1 = S4[pn * 5 + 1], n2 = S4[pn * 5 + 2],
                                      n3 = S4[pn * 5 + 3], n4 = S4[pn * 5 + 4];
-                        const uint32_t type_a = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.z));
-                        const uint32_t type_b = __builtin_amdgcn_readfirstlane(__float_as_uint(q4.w));
-                        if (hit) {
+                        uint32_t type_a = __float_as_uint(q4.z), type_b = __float_as_uint(q4.w);
+                        if (TRACE_SLICES == 1) { // one pair for the whole wave: branch on scalars
+                            type_a = __builtin_amdgcn_readfirstlane(type_a);
+                            type_b = __builtin_amdgcn_readfirstlane(type_b);
+                        }
+                        if (hit && mine_pair) {
                             const uint32_t ka = base + 2 * pr;
                             if (type_a == RTX_PRIM_TRIANGLE && type_b == RTX_PRIM_TRIANGLE) {
                                 bool ok_a = true, ok_b = true;
@@ -143,7 +155,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                         q0 = n0, q1 = n1, q2 = n2, q3 = n3, q4 = n4;
                     }
                 }
-                const bool found = best != RTXD_NONE;
+                // the slices of a ray agree on its nearest hit: smallest distance, then earliest primitive
+#pragma unroll
+                for (uint32_t off = RAYS; off < 64; off <<= 1) {
+                    const float t_o = __shfl_xor(best_t, (int)off);
+                    const uint32_t b_o = (uint32_t)__shfl_xor((int)best, (int)off);
+                    if (b_o != RTXD_NONE && (best == RTXD_NONE || t_o < best_t || (t_o == best_t && b_o < best))) {
+                        best_t = t_o;
+                        best = b_o;
+                    }
+                }
+                const bool found = best != RTXD_NONE && slice == 0;
                 const unsigned long long fmask = __ballot(found);
                 if (fmask) {
                     // one atomic per wave reserves the records of all rays that hit
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
         cur = (next == n + 1) ? ahead : nodes[(next < n_nodes) ? next : n];
         n = next;
     }
-    if (valid) first_rec[local] = head;
+    if (valid && slice == 0) first_rec[local] = head;
     } // tiles
     if (lane == 0 && leaf_prims) atomicAdd(&ctr->leaf_prims, leaf_prims);
 }
