@@ -162,7 +162,8 @@ def main():
     # records of the shading kernel, the gather) overlap with the next frame's kernels.
     n_slots = max(1, args.inflight)
     replicas = [rtx.Scene(desc, local_rank) for _ in range(n_slots)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)]
+    # (one slot: everything on the current stream, which also orders tile reuse)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [torch.cuda.current_stream()]
     gathers = [tiles.FrameGather(torch, dist, h, w, STRIPE_ROWS, world, rank, dev) for _ in range(n_slots)]
     tile_free = [None] * n_slots      # event after which a slot's tile may be overwritten
     pool = ThreadPoolExecutor(max_workers=n_slots)
@@ -175,12 +176,18 @@ def main():
 
     def exchange(slot):
         gathers[slot].run()   # RCCL gather to rank 0 + scatter of the stripes into the frame
-        tile_free[slot] = torch.cuda.Event()
-        tile_free[slot].record()
+        if n_slots > 1:
+            tile_free[slot] = torch.cuda.Event()
+            tile_free[slot].record()
 
     def run_frames(n):
         """n steps; returns the stats of every frame."""
         pending, done = deque(), []
+        if n_slots == 1:                      # nothing to overlap: no thread hand-off either
+            for _ in range(n):
+                done.append(render(0))
+                exchange(0)
+            return done
         for f in range(n):
             slot = f % n_slots
             pending.append((slot, pool.submit(render, slot)))
