@@ -3,8 +3,8 @@
 #pragma once
 
 // ---- trace ------------------------------------------------------------------
-// One wave = the primary rays of an 8 x 8 pixel tile (or a part of one, see TRACE_SLICES).  The wave walks the pre-order
-// box array ONCE for all its rays: `n` is wave-uniform, lane l takes part in box n when
+// One wave = the primary rays of an 8 x 8 pixel tile (with TRACE_SLICES = 2: of 8 x 4
+// pixels, two lanes per ray).  The wave walks the pre-order box array ONCE for all its rays: `n` is wave-uniform, lane l takes part in box n when
 // its own next box n_lane == n.  After an inner box the walk goes to n + 1 if any ray
 // entered it and to its skip link otherwise; a ray that missed an ancestor m waits
 // with n_lane = link(m), and because boxes nest, every waiting ray's link is at or
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     // the block appends its hit records to one shard of the record array
     const uint32_t shard = blockIdx.x % REC_SHARDS, shard_cap = rec_cap / REC_SHARDS;
     unsigned long long leaf_prims = 0;
-    // a block takes the 16 x 16 pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    // a block takes the 16 x TILE_H pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
     const uint32_t i = bx * 16 + (wave & 1) * 8 + (ray & 7);
