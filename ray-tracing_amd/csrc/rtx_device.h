@@ -342,6 +342,7 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
     const v2f uv = u + v;
     ok1 = ok1 && !(v.x < 0.f || uv.x > 1.f);
     ok2 = ok2 && !(v.y < 0.f || uv.y > 1.f);
+    if (EARLY_OUT && !(ok1 || ok2)) return;
     t = f * (e2x * qx + e2y * qy + e2z * qz);
     ok1 = ok1 && t.x > eps;
     ok2 = ok2 && t.y > eps;
