@@ -16,6 +16,15 @@
 #ifndef TRACE_SLICE_MIN_LEAF
 #define TRACE_SLICE_MIN_LEAF 20u
 #endif
+#ifndef TRACE_QUEUE
+#define TRACE_QUEUE 1 // hand the tiles that can hit something out through queues
+#endif
+#ifndef TRACE_QUEUE_MAX_COVER
+#define TRACE_QUEUE_MAX_COVER 0.4 // queues only if the boxes' rectangles cover less of the frame than this
+#endif
+#ifndef TRACE_QUEUE_BLOCKS_PER_CU
+#define TRACE_QUEUE_BLOCKS_PER_CU 4 // resident blocks of the queued trace_kernel (115 VGPRs: 4 waves per SIMD)
+#endif
 #ifndef TRACE_BLOCKS_PER_CU
 #define TRACE_BLOCKS_PER_CU 8 // resident blocks of trace_kernel per CU (8 waves per SIMD)
 #endif

@@ -28,12 +28,20 @@ __device__ __forceinline__ uint8_t clamp_color(float v) {
 __global__ __launch_bounds__(MERGE_BLOCK) void merge_kernel(
     DFrame fr, const DNode *__restrict__ nodes, const DUp *__restrict__ up,
     const DRec *__restrict__ recs, const float4 *__restrict__ colors,
-    const uint32_t *__restrict__ first_rec, uint8_t *__restrict__ rgb) {
+    const uint32_t *__restrict__ first_rec, const uint8_t *__restrict__ traced, uint32_t tile_h,
+    uint8_t *__restrict__ rgb) {
     extern __shared__ float merge_stack[]; // (deepest nesting + 1) * 3 * MERGE_BLOCK floats
     const uint32_t local = blockIdx.x * MERGE_BLOCK + threadIdx.x;
     if (local >= fr.rows * fr.width) return;
     float rx = 0.f, ry = 0.f, rz = 0.f;
-    uint32_t r = first_rec[local];
+    uint32_t r = RTXD_NONE;
+    if (traced) { // only the listed tile parts were traced (tile_list_kernel): the rest hit nothing
+        const uint32_t i = local % fr.width, row = local / fr.width, tiles_x = (fr.width + 15) / 16;
+        const uint32_t part = ((row / tile_h) * tiles_x + (i >> 4)) * 4 + ((i >> 3) & 1) + 2 * ((row % tile_h) / (tile_h / 2));
+        if (traced[part]) r = first_rec[local];
+    } else {
+        r = first_rec[local];
+    }
     if (r != RTXD_NONE && recs[r].next == RTXD_NONE) {
         // One record (the common case): every level from the leaf's up to the top starts
         // black and takes the colour below it iff that is strictly greater than black in

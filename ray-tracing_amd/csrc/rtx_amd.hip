@@ -1,6 +1,8 @@
 // rtx_amd.hip - MI355X (gfx950) render hot path behind the C ABI of include/rtx.h.
 //
-// One frame = four kernels on one stream, no host round trip in between:
+// One frame = these kernels on one stream, no host round trip in between:
+//   tile_list_kernel (when the boxes leave much of the frame empty) lists the tiles of the
+//                    frame that a primary ray can hit anything in
 //   trace_kernel     one lane per pixel: primary ray, box walk, nearest hit per
 //                    leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
 //   classify_kernel  one lane per hit record: the record goes to the work list of its
@@ -74,6 +76,9 @@ struct rtx_scene {
     uint32_t rec_cap = 0;
     uint32_t *d_first = nullptr;
     uint64_t pix_cap = 0;
+    uint32_t *d_tiles = nullptr; // tile queues of the trace kernel, then one flag byte per tile part
+    uint64_t tile_cap = 0;
+    std::vector<float> top_boxes; // lb, rt of every top-level box (6 floats each)
     uint8_t *d_rgb = nullptr; // staging for rtx_render's host output
     uint64_t rgb_cap = 0;
     DCounters *d_ctr = nullptr;
@@ -166,6 +171,7 @@ extern "C" void rtx_scene_destroy(rtx_scene *s) {
     (void)hipFree(s->d_colors);
     (void)hipFree(s->d_first);
     (void)hipFree(s->d_rgb);
+    (void)hipFree(s->d_tiles);
     (void)hipFree(s->d_ctr);
     if (s->h_ctr) (void)hipHostFree(s->h_ctr);
     for (auto &e : s->ev)
@@ -330,6 +336,11 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     s->n_nodes = NK;
     s->nest_levels = nest_levels;
+    for (uint32_t n = 0; n < NK;) { // top-level boxes: skip every subtree
+        s->top_boxes.insert(s->top_boxes.end(), nodes[n].lb, nodes[n].lb + 3);
+        s->top_boxes.insert(s->top_boxes.end(), nodes[n].rt, nodes[n].rt + 3);
+        n = (nodes[n].info == RTXD_NONE) ? nodes[n].link : n + 1;
+    }
     s->wide_dets = wide_dets;
     s->trace_slices = (desc->n_leaves && desc->n_prims / desc->n_leaves >= TRACE_SLICE_MIN_LEAF) ? 2u : 1u;
     s->n_prims = desc->n_prims;
@@ -397,6 +408,64 @@ static rtx_status ensure_records(rtx_scene *s, uint64_t need) {
     return RTX_OK;
 }
 
+// Pixel rectangles of the top-level boxes: the eye, a pixel's ray origin on the plane
+// z = 1000 and every point of its ray are collinear (primary_ray), so the rays that can
+// enter a box are those whose pixel lies in the perspective projection of the box from
+// the eye onto that plane, a convex set inside the bounding rectangle of the eight
+// projected corners.  Two pixels are added all round (the kernels' float arithmetic differs
+// from this one by a tiny fraction of a pixel).  A box that reaches the eye's height, or an
+// eye at or below the plane, gives the whole frame.  Returns the fraction of the frame the
+// rectangles cover at most (their areas summed).
+static double tile_rects(const rtx_scene *s, const rtx_params *p, DTileRects *out) {
+    const double W = p->width, H = p->height, sc = 1000.0 / H;
+    const double cx = p->camera[0], cy = p->camera[1], cz = p->camera[2];
+    const size_t n_boxes = s->top_boxes.size() / 6;
+    out->n = 0;
+    bool whole = !(cz > 1000.0 + 1e-3) || n_boxes == 0;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300, area = 0.0; // union, for too many boxes
+    for (size_t b = 0; b < n_boxes && !whole; b++) {
+        const float *q = &s->top_boxes[b * 6];
+        double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+        for (int c = 0; c < 8 && !whole; c++) {
+            const double qx = q[(c & 1) ? 3 : 0], qy = q[(c & 2) ? 4 : 1], qz = q[(c & 4) ? 5 : 2];
+            const double below = cz - qz; // the corner must lie below the eye
+            if (!(below > 1e-6 * (fabs(cz) + fabs(qz) + 1.0))) {
+                whole = true;
+                break;
+            }
+            const double lam = (cz - 1000.0) / below;
+            const double i = (cx + (qx - cx) * lam - 500.0) / sc + W * 0.5, j = (cy + (qy - cy) * lam) / sc;
+            if (!(fabs(i) < 1e12 && fabs(j) < 1e12)) {
+                whole = true;
+                break;
+            }
+            bx0 = std::min(bx0, i), bx1 = std::max(bx1, i), by0 = std::min(by0, j), by1 = std::max(by1, j);
+        }
+        if (whole) break;
+        bx0 = std::max(0.0, floor(bx0) - 2.0), by0 = std::max(0.0, floor(by0) - 2.0);
+        bx1 = std::min(W - 1.0, ceil(bx1) + 2.0), by1 = std::min(H - 1.0, ceil(by1) + 2.0);
+        if (bx0 > bx1 || by0 > by1) continue; // off the frame
+        area += (bx1 - bx0 + 1.0) * (by1 - by0 + 1.0);
+        x0 = std::min(x0, bx0), x1 = std::max(x1, bx1), y0 = std::min(y0, by0), y1 = std::max(y1, by1);
+        if (out->n < TILE_RECTS) {
+            out->x0[out->n] = (int32_t)bx0, out->x1[out->n] = (int32_t)bx1;
+            out->y0[out->n] = (int32_t)by0, out->y1[out->n] = (int32_t)by1;
+        }
+        out->n++;
+    }
+    if (whole) {
+        out->n = 1;
+        out->x0[0] = 0, out->y0[0] = 0, out->x1[0] = (int32_t)p->width - 1, out->y1[0] = (int32_t)p->height - 1;
+        return 1.0;
+    }
+    if (out->n > TILE_RECTS) { // more boxes than rectangles: one rectangle around all of them
+        out->n = 1;
+        out->x0[0] = (int32_t)x0, out->x1[0] = (int32_t)x1, out->y0[0] = (int32_t)y0, out->y1[0] = (int32_t)y1;
+        area = (x1 - x0 + 1.0) * (y1 - y0 + 1.0);
+    }
+    return std::min(1.0, area / (W * H));
+}
+
 // Enqueue and complete one frame.  On return s->h_ctr holds the frame's counters.
 static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb, hipStream_t st,
                                rtx_stats *stats) {
@@ -437,6 +506,19 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
     const uint32_t tile_h = 16 / s->trace_slices;
     const uint32_t tiles = ((p->width + 15) / 16) * ((rows + tile_h - 1) / tile_h);
+    // Tiles through queues when the boxes leave a good part of the frame empty: only the
+    // tile parts that can hit something are traced, each by the next free wave.  Where
+    // nearly every tile has work the fixed assignment is cheaper.
+    const uint32_t tile_seg = 4 * ((tiles + TILE_QUEUES - 1) / TILE_QUEUES); // entries per tile queue
+    DTileRects rects;
+    const bool queued = TRACE_QUEUE && tile_rects(s, p, &rects) < TRACE_QUEUE_MAX_COVER;
+    uint8_t *d_traced = nullptr;
+    if (queued) {
+        const uint64_t words = (uint64_t)tile_seg * TILE_QUEUES + ((uint64_t)tiles * 4 + 3) / 4;
+        if (hipError_t e = grow(&s->d_tiles, &s->tile_cap, words); e != hipSuccess)
+            return fail(RTX_ERR_NOMEM, std::string("tile queues: ") + hipGetErrorString(e));
+        d_traced = reinterpret_cast<uint8_t *>(s->d_tiles + (uint64_t)tile_seg * TILE_QUEUES);
+    }
     // the queue-driven shading kernels get exactly the waves that are resident at once
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
@@ -448,12 +530,25 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     for (int attempt = 0; attempt < 3; attempt++) {
         HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
+#define LAUNCH_TRACE(SL)                                                                                     \
+    do {                                                                                                     \
+        if (queued) {                                                                                        \
+            tile_list_kernel<SL><<<(tiles * 4 + 255) / 256, 256, 0, st>>>(fr, rects, d_traced, s->d_tiles,   \
+                                                                         tile_seg, s->d_ctr);                \
+            trace_kernel<SL, true><<<(uint32_t)s->n_cu * TRACE_QUEUE_BLOCKS_PER_CU, TRACE_BLOCK, 0, st>>>(   \
+                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_tiles,       \
+                tile_seg, s->d_ctr);                                                                         \
+        } else {                                                                                             \
+            trace_kernel<SL, false><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(        \
+                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, nullptr, 0,       \
+                s->d_ctr);                                                                                   \
+        }                                                                                                    \
+    } while (0)
         if (s->trace_slices == 2)
-            trace_kernel<2><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(
-                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_ctr);
+            LAUNCH_TRACE(2);
         else
-            trace_kernel<1><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(
-                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_ctr);
+            LAUNCH_TRACE(1);
+#undef LAUNCH_TRACE
 #define LAUNCH_FEW(G)                                                                                        \
     do {                                                                                                     \
         if (ieee)                                                                                            \
@@ -489,7 +584,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         }
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
         merge_kernel<<<merge_blocks, MERGE_BLOCK, (size_t)s->nest_levels * 3 * MERGE_BLOCK * sizeof(float), st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
-                                                          s->d_colors, s->d_first, d_rgb);
+                                                          s->d_colors, s->d_first, d_traced, tile_h, d_rgb);
         if (timing) HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, offsetof(DCounters, head), hipMemcpyDeviceToHost, st));

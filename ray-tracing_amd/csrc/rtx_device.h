@@ -109,6 +109,13 @@ struct DFrame {
 #endif
 
 // Counters of one frame (device memory, zeroed before the trace kernel).
+#define TILE_QUEUES 64u // = lanes of a wave (a wave looks at all of them at once)
+#define TILE_RECTS 8    // pixel rectangles (one per top-level box) a frame's tiles are checked against
+// Pixel rectangles (inclusive, global rows) outside of which no primary ray enters a box.
+struct DTileRects {
+    uint32_t n;
+    int32_t x0[TILE_RECTS], x1[TILE_RECTS], y0[TILE_RECTS], y1[TILE_RECTS];
+};
 #ifndef QUEUE_HEADS
 #define QUEUE_HEADS 64u // queue heads per work list (a power of two, at most 64: one per lane)
 #endif
@@ -141,7 +148,14 @@ struct DCounters {
     struct {
         uint32_t next;
         uint32_t pad[31];
-    } head[WORK_LISTS][QUEUE_HEADS]; // last member: the host reads the counters back up to here
+    } head[WORK_LISTS][QUEUE_HEADS]; // the host reads the counters back up to here
+    // Tile parts of the frame in which a primary ray may enter a top-level box, in TILE_QUEUES
+    // lists (tile_list_kernel fills them, trace_kernel takes its work from them).
+    struct {
+        uint32_t count;
+        uint32_t next;
+        uint32_t pad[30];
+    } tiles[TILE_QUEUES];
 };
 
 // ---- the sharded record array --------------------------------------------------

@@ -13,11 +13,11 @@
 // seeing its own boxes in the reference's order (raytracing.h:74-98).  Box and
 // triangle data are therefore wave-uniform: scalar loads (next one already in flight),
 // used as SGPR operands; only the rays live in VGPRs.
-template <uint32_t TRACE_SLICES>
+template <uint32_t TRACE_SLICES, bool QUEUED>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     DFrame fr, const DNode *__restrict__ nodes, uint32_t n_nodes, const DPrim *__restrict__ prims,
     DRec *__restrict__ recs, uint32_t rec_cap, uint32_t *__restrict__ first_rec,
-    DCounters *__restrict__ ctr) {
+    const uint32_t *__restrict__ tile_list, uint32_t tile_seg, DCounters *__restrict__ ctr) {
     // A wave takes 8 x (8 / TRACE_SLICES) pixels; lane l carries ray l % RAYS and, in a leaf,
     // tests every TRACE_SLICES-th pair of primitives, starting with pair l / RAYS.
     constexpr uint32_t RAYS = 64 / TRACE_SLICES, TILE_H = 16 / TRACE_SLICES;
@@ -31,10 +31,37 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     const uint32_t shard = blockIdx.x % REC_SHARDS, shard_cap = rec_cap / REC_SHARDS;
     unsigned long long leaf_prims = 0;
     // a block takes the 16 x TILE_H pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // (QUEUED: every wave takes the next tile part of a queue instead; tile_list_kernel has
+    // listed the tile parts in which a ray may enter a top-level box)
+    uint32_t next_tile = blockIdx.x, queue = blockIdx.x % TILE_QUEUES, moves = 0;
+    for (;;) {
+    uint32_t tile, sub = wave;
+    if constexpr (QUEUED) {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&ctr->tiles[queue].next, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= ctr->tiles[queue].count) { // this queue is used up: go on with one that is not, if any
+            const uint32_t taken = __hip_atomic_load(&ctr->tiles[lane].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_open = taken < ctr->tiles[lane].count;
+            const unsigned long long open = __ballot(is_open);
+            if (open == 0) break;
+            const uint32_t pick = (blockIdx.x * (TRACE_BLOCK / 64) + wave + moves++) % (uint32_t)__popcll(open);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(open >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)open, 0u));
+            queue = (uint32_t)__ffsll((long long)__ballot(is_open && rank == pick)) - 1u;
+            continue;
+        }
+        const uint32_t part = tile_list[queue * tile_seg + k];
+        tile = part >> 2;
+        sub = part & 3u;
+    } else {
+        tile = next_tile;
+        next_tile += gridDim.x;
+        if (tile >= n_tiles) break;
+    }
     const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
-    const uint32_t i = bx * 16 + (wave & 1) * 8 + (ray & 7);
-    const uint32_t r = by * TILE_H + (wave >> 1) * (TILE_H / 2) + (ray >> 3);
+    const uint32_t i = bx * 16 + (sub & 1) * 8 + (ray & 7);
+    const uint32_t r = by * TILE_H + (sub >> 1) * (TILE_H / 2) + (ray >> 3);
     const bool valid = i < fr.width && r < fr.rows;
     if (!__any(valid) || n_nodes == 0) {
         if (valid && slice == 0) first_rec[r * fr.width + i] = RTXD_NONE;
@@ -223,4 +250,37 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     if (valid && slice == 0) first_rec[local] = head;
     } // tiles
     if (lane == 0 && leaf_prims) atomicAdd(&ctr->leaf_prims, leaf_prims);
+}
+
+// First pass of a frame when the tiles are queued: one lane per tile part (one wave's
+// pixels of trace_kernel: tile * 4 + part).  A part goes to queue tile % TILE_QUEUES if it
+// meets one of the frame's pixel rectangles (the projections of the top-level boxes onto the
+// image, widened: a ray outside all of them enters no box and hits nothing,
+// raytracing.h:74-98); flag[] tells merge_kernel which parts were traced at all.  A queue
+// holds at most tile_seg = 4 * ceil(n_tiles / TILE_QUEUES) entries.
+template <uint32_t TRACE_SLICES>
+__global__ __launch_bounds__(256) void tile_list_kernel(DFrame fr, DTileRects rc, uint8_t *__restrict__ flag,
+                                                         uint32_t *__restrict__ tile_list, uint32_t tile_seg,
+                                                         DCounters *__restrict__ ctr) {
+    constexpr uint32_t TILE_H = 16 / TRACE_SLICES;
+    const uint32_t tiles_x = (fr.width + 15) / 16;
+    const uint32_t n_tiles = tiles_x * ((fr.rows + TILE_H - 1) / TILE_H);
+    const uint32_t part = blockIdx.x * blockDim.x + threadIdx.x;
+    if (part >= n_tiles * 4) return;
+    const uint32_t tile = part >> 2, sub = part & 3u;
+    const uint32_t bx = tile % tiles_x, by = tile / tiles_x;
+    const uint32_t x0 = bx * 16 + (sub & 1) * 8, r0 = by * TILE_H + (sub >> 1) * (TILE_H / 2);
+    bool any = false;
+    if (x0 < fr.width && r0 < fr.rows) {
+        const int32_t x1 = (int32_t)min(x0 + 7, fr.width - 1);
+        const int32_t g0 = (int32_t)part_row(fr, r0), g1 = (int32_t)part_row(fr, min(r0 + TILE_H / 2 - 1, fr.rows - 1));
+        for (uint32_t k = 0; k < rc.n; k++)
+            any = any || !(x1 < rc.x0[k] || (int32_t)x0 > rc.x1[k] || g1 < rc.y0[k] || g0 > rc.y1[k]);
+    }
+    flag[part] = any ? 1 : 0;
+    if (any) {
+        const uint32_t q = tile % TILE_QUEUES;
+        const uint32_t k = atomicAdd(&ctr->tiles[q].count, 1u);
+        tile_list[q * tile_seg + k] = part;
+    }
 }

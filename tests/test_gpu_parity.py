@@ -410,6 +410,33 @@ def test_render_image_drop_in(op, capi, scenes, built, tmp_path):
     assert open(path3, "rb").read() == data
 
 
+@pytest.mark.parametrize("cfg,camera", [
+    ("buddha", (500.0, 500.0, 3000.0)),
+    ("buddha", (900.0, 120.0, 1400.0)),     # off-axis and close: the mesh runs off the frame
+    ("buddha", (500.0, 500.0, 1001.0)),     # eye just above the image plane: rays nearly parallel to it
+    ("buddha", (500.0, 500.0, 1000.0)),     # eye on the plane, and below it: no projection, whole frame
+    ("buddha", (500.0, 500.0, 400.0)),
+    ("multi", (-800.0, 1700.0, 2200.0)),
+    ("dino_spheres", (500.0, 500.0, 1200.0)),
+])
+def test_cameras_and_tile_queues(op, capi, built, cfg, camera):
+    """The primary-ray kernel traces only the tiles that meet the projection of a top-level
+    box onto the image (when those leave enough of the frame empty): no hit may be lost for
+    any eye position, including those for which no projection exists."""
+    _, d, sc = built(cfg)
+    p = capi.default_params(480, 270, 3, 9)
+    p.camera[:] = camera
+    rgb_g, hits_g = sc.render_hits(p)
+    rgb_c, _, hits_c, _ = op.render(d, p)
+    check_hits(hits_g, hits_c, color_tol=3e-3)
+    check_rgb(rgb_g, rgb_c)
+    p.stripe_rows, p.n_parts, p.part = 3, 4, 1   # rows of a part map to scattered rows of the frame
+    rgb_g, hits_g = sc.render_hits(p)
+    rgb_c, _, hits_c, _ = op.render(d, p)
+    check_hits(hits_g, hits_c, color_tol=3e-3)
+    assert np.array_equal(rgb_g, rgb_c) or check_rgb(rgb_g, rgb_c) >= 0
+
+
 def test_bench_line_and_frames_in_flight():
     """bench.py end to end on the smallest mesh workload: one JSON line with the roofline
     and CPU-baseline objects, and with two frames in flight the assembled frames of both
