@@ -19,6 +19,9 @@
 #ifndef TRACE_QUEUE
 #define TRACE_QUEUE 1 // hand the tiles that can hit something out through queues
 #endif
+#ifndef TRACE_SLICES_QUEUED
+#define TRACE_SLICES_QUEUED 2u // lanes per primary ray in scenes with large leaves when the tiles are queued (4: faster only on small shares of a frame)
+#endif
 #ifndef TRACE_QUEUE_MAX_COVER
 #define TRACE_QUEUE_MAX_COVER 0.4 // queues only if the boxes' rectangles cover less of the frame than this
 #endif

@@ -504,14 +504,16 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (rs != RTX_OK) return rs;
     }
     const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
-    const uint32_t tile_h = 16 / s->trace_slices;
-    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + tile_h - 1) / tile_h);
     // Tiles through queues when the boxes leave a good part of the frame empty: only the
     // tile parts that can hit something are traced, each by the next free wave.  Where
     // nearly every tile has work the fixed assignment is cheaper.
-    const uint32_t tile_seg = 4 * ((tiles + TILE_QUEUES - 1) / TILE_QUEUES); // entries per tile queue
     DTileRects rects;
     const bool queued = TRACE_QUEUE && tile_rects(s, p, &rects) < TRACE_QUEUE_MAX_COVER;
+    // lanes per primary ray: with queues the extra waves walk only the listed tiles
+    const uint32_t slices = (queued && s->trace_slices == 2) ? TRACE_SLICES_QUEUED : s->trace_slices;
+    const uint32_t tile_h = 16 / slices;
+    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + tile_h - 1) / tile_h);
+    const uint32_t tile_seg = 4 * ((tiles + TILE_QUEUES - 1) / TILE_QUEUES); // entries per tile queue
     uint8_t *d_traced = nullptr;
     if (queued) {
         const uint64_t words = (uint64_t)tile_seg * TILE_QUEUES + ((uint64_t)tiles * 4 + 3) / 4;
@@ -544,7 +546,9 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
                 s->d_ctr);                                                                                   \
         }                                                                                                    \
     } while (0)
-        if (s->trace_slices == 2)
+        if (slices == 4)
+            LAUNCH_TRACE(4);
+        else if (slices == 2)
             LAUNCH_TRACE(2);
         else
             LAUNCH_TRACE(1);
