@@ -29,7 +29,14 @@
 // sample loop then walks only those.  Leaves too large for the list are
 // screened in segments, once per pass.
 #define CAND_MAX 512
-#define CULL_MARGIN 0.5f // world units; start points drift by < 0.1 through rounding
+// Margin of the candidate screens, in world units.  It has to cover what separates the
+// screens' geometry from the float arithmetic it stands for: the start points of a record
+// leave the straight segment between the first and the last by the rounding of up to
+// ~1000 additions (< 0.03 at coordinates around 1000), and the triangle test's own
+// rounding (~1e-5 as a distance).
+#ifndef CULL_MARGIN
+#define CULL_MARGIN 0.1f
+#endif
 
 #define PASS_SAMPLES 128 // light samples per pass: two per lane
 

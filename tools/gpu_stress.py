@@ -10,7 +10,8 @@ RGB within 1/255 on >= 99.9 % of the pixels, per-record colours within 5e-3 of
 |channel| + 0.01 + a thousandth of the record's largest channel (with the light inside
 the scene or a negative acne offset, contributions of both signs cancel in a record's sum
 and the order of the sum shows: a channel of 0.005 beside one of 135 came out 3e-4 apart,
-with the IEEE build of the BSDF as well; the GPU tests hold ordinary frames to 1e-3).
+with the IEEE build of the BSDF as well; 1e-2 with mirror bounces, which add the folded
+colours of the deeper levels; the GPU tests hold ordinary frames to 1e-3).
 """
 import importlib
 import os
@@ -82,7 +83,7 @@ for case in range(n_cases):
         # noise of the record's large channels: measure it against those as well
         rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
         rel = float((np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-2 + 1e-3 * rec_max)).max())
-    ok = ok_ids and ok_t and ok_lit and within >= 0.999 and rel < 5e-3
+    ok = ok_ids and ok_t and ok_lit and within >= 0.999 and rel < (1e-2 if max_depth else 5e-3)
     bad += not ok
     print("%s case %2d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s "
           "(%d vs %d) part %d/%d cam %s rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
