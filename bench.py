@@ -96,8 +96,50 @@ def cpu_baseline(scenes, name, w, h, nl):
     dt = time.perf_counter() - t0
     rays = st.primary_rays + st.shadow_rays
     threads = oracle_py.oracle().orc_max_threads()
+    # one thread, on a thinner sample of the same frame sized to ~8 s from the rate just measured
+    parts1 = max(2, min(256, int(round(p.n_parts * threads * dt / 8.0))))
+    p1 = oracle_py.capi.default_params(w, h, nl, 1)
+    p1.stripe_rows, p1.n_parts, p1.part = STRIPE_ROWS, parts1, parts1 // 2
+    t0 = time.perf_counter()
+    _, _, _, st1 = oracle_py.render(d, p1, want_hits=False, want_rgb=False, threads=1)
+    dt1 = time.perf_counter() - t0
+    rays1 = st1.primary_rays + st1.shadow_rays
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%s of %s, %d rays in %.2f s" % (sample, name, rays, dt)}
+            "sample": "%s of %s, %d rays in %.2f s" % (sample, name, rays, dt),
+            "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                           "sample": "one stripe of %d rows in every %d of %s, %d rays in %.2f s"
+                                     % (STRIPE_ROWS, parts1, name, rays1, dt1)}}
+
+
+def spawn_ranks(n):
+    """One child process per GPU (the same command line, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in its environment), as `python -m torch.distributed.run --nproc-per-node n`
+    would start them.  Rank 0 prints the JSON line on the inherited stdout.  Returns the
+    exit code: 0 when every rank succeeded, else the first failure's (the other ranks are
+    then terminated by their process ids)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, live = 0, list(children)
+    while live:
+        time.sleep(0.05)
+        for c in list(live):
+            code = c.poll()
+            if code is None:
+                continue
+            live.remove(c)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for other in live:          # a rank failed: the others would wait for it forever
+                    other.terminate()
+    return rc
 
 
 def main():
@@ -112,9 +154,17 @@ def main():
                          "HIP-event duration then includes the time it shares the GPU, so the roofline "
                          "figures are only meaningful with 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-steps", type=int, default=5,
+                    help="frames rendered through rtx_render (host output, PCIe read-back included) after "
+                         "the timed region, reported as ms_per_step_host; 0 = skip")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region compare the assembled frames with a full-frame render")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process becomes the launcher of
+        # the N ranks.  It has not touched the GPU (nor imported torch) at this point.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -123,9 +173,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with "
-                             "python -m torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
@@ -226,24 +273,43 @@ def main():
         counts[0] = mx[0]
     elapsed, primary, shadow, tests, hits, lit, tests_run = [float(x) for x in counts.tolist()]
 
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    # the same frames through rtx_render (host output buffer: the PCIe read-back is part of
+    # the call), outside the timed region; never `value`
+    host_ms = None
+    if args.host_steps > 0:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.host_steps):
+            replicas[0].render(p)
+        host_ms = (time.perf_counter() - t0) / args.host_steps * 1e3
+        if world > 1:
+            hm = torch.tensor([host_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(hm, op=dist.ReduceOp.MAX)
+            host_ms = float(hm.item())
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         rays = primary + shadow
-        # roofline of the shadow/shade kernel on this rank (rank 0's share of the frame)
+        # roofline of the shadow/shade kernel on this rank (rank 0's share of the frame):
+        # the work the kernel EXECUTED (tests left after its screens, rays, shaded samples)
+        # over its average HIP-event duration, against the FP32 vector peak
         k = args.steps
         shade_avg_ms = shade_ms / k
-        flop = (st.shadow_tests * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
-                st.lit_samples * FLOP_PER_SHADED_SAMPLE)
-        achieved = flop / (shade_avg_ms * 1e-3) / 1e12 if shade_avg_ms > 0 else 0.0
+        sec = shade_avg_ms * 1e-3
+        flop_alg = (st.shadow_tests * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
+                    st.lit_samples * FLOP_PER_SHADED_SAMPLE)
         flop_run = (st.shadow_tests_run * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
                     st.lit_samples * FLOP_PER_SHADED_SAMPLE)
-        alg_bytes = st.shadow_tests * BYTES_PER_PRIM_TEST
+        achieved = flop_run / sec / 1e12 if sec > 0 else 0.0
+        traffic = hbm_traffic(args.workload)
         out = {
             "metric": "Mrays/s (primary+shadow)",
             "value": rays / (elapsed / args.steps) / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_host": host_ms,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -253,31 +319,35 @@ def main():
                        "parallelism": "row stripes dealt to %d GPU(s), scene replicated, RCCL gather" % world,
                        "primary_rays": int(primary), "shadow_rays": int(shadow), "hit_records": int(hits)},
             "roofline": {
-                "kernel": "shade_kernel", "bound": "mfma",
-                "bound_note": "compute bound on the FP32 vector ALUs (VALU busy ~90 % in the PMC profile); priced "
-                              "against the FP32 peak, which is the same 157.3 TFLOP/s for the vector and the "
-                              "matrix pipes on MI355X. No MFMA is issued: the path has no dense contraction, and "
-                              "bit-exact hit ids forbid fused multiply-adds, so un-fused packed arithmetic tops "
-                              "out at peak_unfused",
+                "kernel": "shade_kernel", "bound": "valu",
+                "bound_note": "FP32 vector ALUs (no MFMA is issued: the path has no dense contraction). peak "
+                              "counts a fused multiply-add as 2 FLOP; bit-exact hit ids forbid contraction, so "
+                              "packed un-fused arithmetic tops out at peak_unfused",
                 "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                 "peak_unfused": PEAK_FP32_UNFUSED_TFLOPS,
                 "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
-                "traffic": hbm_traffic(args.workload),
+                "traffic": traffic,
                 "launch_ms": shade_avg_ms,
-                "algorithmic_flop_per_launch": flop,
                 "executed_flop_per_launch": flop_run,
-                "executed_tflops": flop_run / (shade_avg_ms * 1e-3) / 1e12 if shade_avg_ms > 0 else 0.0,
-                "frac_executed": (flop_run / (shade_avg_ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS) if shade_avg_ms > 0 else 0.0,
+                "flop_per_unit": {"prim_test": FLOP_PER_PRIM_TEST, "shadow_ray": FLOP_PER_SHADOW_RAY,
+                                  "shaded_sample": FLOP_PER_SHADED_SAMPLE},
+                "units_per_launch": {"prim_tests_run": int(st.shadow_tests_run), "shadow_rays": int(st.shadow_rays),
+                                     "shaded_samples": int(st.lit_samples)},
                 "tests_run_fraction": st.shadow_tests_run / max(st.shadow_tests, 1),
-                "note": "achieved = work the reference's algorithm does for these rays (every leaf primitive "
-                        "tested for every shadow ray) / kernel time; the kernel rules out part of those tests "
-                        "per record with a conservative geometric screen (executed_* = what it really ran), which "
-                        "is how the algorithmic rate can exceed the hardware peak",
-                "hbm": {"bound": "hbm", "achieved": alg_bytes / (shade_avg_ms * 1e-3) / 1e9 if shade_avg_ms > 0 else 0.0,
+                # what the reference's algorithm would have done for the same rays (every leaf
+                # primitive tested for every shadow ray): a speed-up equivalent, not a hardware rate
+                "algorithmic_equivalent": {
+                    "flop_per_launch": flop_alg,
+                    "tflops": flop_alg / sec / 1e12 if sec > 0 else 0.0,
+                    "bytes_per_launch": st.shadow_tests * BYTES_PER_PRIM_TEST,
+                    "note": "work of the reference's loop nest / kernel time; the kernel proves most of those "
+                            "tests unnecessary per record, so this can exceed the hardware peak"},
+                "hbm": {"bound": "hbm", "achieved": (traffic / sec / 1e9) if (traffic and sec > 0) else None,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": (alg_bytes / (shade_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if shade_avg_ms > 0 else 0.0,
-                        "note": "algorithmic bytes as if every test fetched its triangle; the scene is cache resident"},
+                        "frac": (traffic / sec / 1e9 / PEAK_HBM_GBS) if (traffic and sec > 0) else None,
+                        "note": "measured HBM bytes of one launch (rocprofv3 PMC passes, profiles/hbm_traffic.json) "
+                                "/ launch time: the scene is cache resident, HBM is not the bound"},
             },
             "kernel_ms": {"trace": trace_ms / k, "shade": shade_avg_ms, "merge": merge_ms / k},
         }

@@ -451,11 +451,40 @@ def test_bench_line_and_frames_in_flight():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["unit"] == "Mrays/s" and line["n_gpus"] == 1 and line["value"] > 0
-    assert line["roofline"]["kernel"] == "shade_kernel" and 0 < line["roofline"]["frac"] < 1.5
+    roof = line["roofline"]
+    assert roof["kernel"] == "shade_kernel" and roof["bound"] == "valu" and 0 < roof["frac"] < 1.0
+    # frac is the executed work over the launch time, recomputable from the line itself
+    units, per = roof["units_per_launch"], roof["flop_per_unit"]
+    flop = (units["prim_tests_run"] * per["prim_test"] + units["shadow_rays"] * per["shadow_ray"] +
+            units["shaded_samples"] * per["shaded_sample"])
+    assert flop == roof["executed_flop_per_launch"]
+    assert abs(flop / (roof["launch_ms"] * 1e-3) / 1e12 / roof["peak"] - roof["frac"]) < 1e-9
+    assert line["ms_per_step_host"] > 0 and line["ranks_seen"] == 1
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert line["cpu_baseline"]["one_thread"]["cores"] == 1 and line["cpu_baseline"]["one_thread"]["value"] > 0
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bunny", "--steps", "4",
                           "--warmup", "2", "--inflight", "2", "--verify", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "verify slot 1: assembled frame equals" in out.stderr
     assert json.loads(out.stdout.strip().splitlines()[-1])["config"]["frames_in_flight"] == 2
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with nothing else: the process starts its two ranks itself
+    (one per GPU on a multi-GPU node; here both share the box's GPU and talk over gloo,
+    a rehearsal of the path, not a measurement) and rank 0 prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTX_BENCH_BACKEND="gloo", RTX_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "bunny",
+                          "--steps", "3", "--warmup", "1", "--verify"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
+    assert "verify slot 0: assembled frame equals" in out.stderr

@@ -51,3 +51,20 @@ def test_gather_over_gloo(tmp_path, world):
         assert p.wait(timeout=180) == 0
     got, want = np.load(out)
     assert np.array_equal(got, want)
+
+
+def test_bench_launcher_reports_failing_ranks():
+    """`python bench.py --gpus 2` starts its own ranks; without a GPU every rank refuses to
+    run, and the launcher must end with a non-zero exit code (not hang, not print a line)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "bunny"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert out.stderr.count("bench.py needs a GPU") == 2
