@@ -221,10 +221,36 @@ rtx_status rtx_render(rtx_scene *scene, const rtx_params *p, uint8_t *rgb_host,
 
 /* Same, output left in device memory (d_rgb: device pointer on the scene's
  * device) and work enqueued on `hip_stream` (a hipStream_t, NULL = the null
- * stream).  Returns after the work is complete when stats != NULL, else as
- * soon as it is enqueued. */
+ * stream).  The call is synchronous on that stream: it returns after the
+ * frame is complete (the host reads the frame's counters back to detect a
+ * full record buffer), with or without stats. */
 rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
                              void *hip_stream, rtx_stats *stats);
+
+/* rtx_render_device for callers that cannot allocate.  No counterpart in the
+ * reference: it exists for callers that may not call hipMalloc / hipFree
+ * while they render (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation).  Same arguments, same kernels and the
+ * same output bytes as rtx_render_device, but every per-frame work buffer
+ * (hit records, their colours and work lists, one record head per pixel,
+ * tile queues, counters) is carved from a static device array of
+ * RTX_STATIC_SCRATCH_BYTES that each GPU the library runs on holds from the
+ * first rtx_scene_create on it until the process ends; the call allocates
+ * and frees nothing.  The caller still passes the scene and d_rgb.
+ *   Limits: 4 bytes per rendered pixel plus the tile queues come out of the
+ * array first and what is left holds the hit records (96 bytes each).  A
+ * frame that leaves room for fewer than RTX_STATIC_MIN_RECORDS records, or
+ * that produces more hit records than fit (in any of the 8 equal shards of
+ * the record array), fails with RTX_ERR_LIMIT and a message; nothing is
+ * retried or grown.  As a guide: 3840 x 2160 leaves about 340 000 records,
+ * 1920 x 1080 about 610 000.
+ *   All calls on one GPU share that GPU's array (whatever the scene or
+ * stream): calls that overlap in time on one GPU race and give undefined
+ * frames; calls on different GPUs are independent. */
+#define RTX_STATIC_SCRATCH_BYTES (64u << 20)
+#define RTX_STATIC_MIN_RECORDS 4096u
+rtx_status rtx_render_device_static(rtx_scene *scene, const rtx_params *p, void *d_rgb,
+                                    void *hip_stream, rtx_stats *stats);
 
 /* Render and also return the per-(pixel, leaf) hit records, sorted by
  * (pixel, ordinal).  At most `capacity` records are written; *n_hits receives

@@ -44,6 +44,7 @@ def lib():
         L.rtx_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
         L.rtx_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                         C.POINTER(Stats)]
+        L.rtx_render_device_static.argtypes = L.rtx_render_device.argtypes
         L.rtx_render_hits.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64,
                                       C.POINTER(C.c_uint64), C.c_void_p]
         _lib = L
@@ -101,6 +102,14 @@ class Scene:
         st = Stats() if stats else None
         _check(lib().rtx_render_device(self._h, C.byref(p), C.c_void_p(d_rgb), C.c_void_p(stream),
                                        C.byref(st) if stats else None))
+        return st
+
+    def render_device_static(self, p, d_rgb, stream=0):
+        """rtx_render_device_static: the same frame with every work buffer taken from the
+        library's static device array (the call allocates nothing)."""
+        st = Stats()
+        _check(lib().rtx_render_device_static(self._h, C.byref(p), C.c_void_p(d_rgb), C.c_void_p(stream),
+                                              C.byref(st)))
         return st
 
     def render_hits(self, p):

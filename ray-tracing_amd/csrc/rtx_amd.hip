@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,42 @@ static rtx_status fail(rtx_status s, const std::string &msg) {
         if (e_ != hipSuccess)                                                              \
             return fail(RTX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
+
+// ---- static work area of rtx_render_device_static ---------------------------------
+// Per-frame work buffers (hit records, colours and work lists, per-pixel record heads,
+// tile queues, counters) for callers that may not allocate.  Every device the library
+// runs on holds its own copy of the array until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress: the address the kernels get is
+// the one resolved per device in scratch_resolve().
+#define STATIC_SCRATCH_BYTES RTX_STATIC_SCRATCH_BYTES
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+#define SCRATCH_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static unsigned char *g_scratch_ptr[SCRATCH_MAX_DEVICES]; // per device: address of its copy of `scratch`
+
+// Resolves the address of `device`'s copy of the work area, once.  The device must be current.
+static rtx_status scratch_resolve(int device) {
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return RTX_OK; // no static work area on this device
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RTX_OK;
+    unsigned char *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RTX_ERR_HIP, "hipGetSymbolAddress returned a null address for the static work area");
+    g_scratch_ptr[device] = ptr;
+    return RTX_OK;
+}
+
+// The work buffers of one frame: the scene's own (grown on demand) or a carving of the
+// static work area (fixed).
+struct FrameBufs {
+    DRec *recs = nullptr;
+    float4 *colors = nullptr; // rec_cap colours followed by the work lists
+    uint32_t rec_cap = 0;
+    uint32_t *first = nullptr;
+    uint32_t *tiles = nullptr;
+    DCounters *ctr = nullptr;
+};
 
 struct rtx_scene {
     int device = 0;
@@ -330,6 +367,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+    if (rtx_status rs = scratch_resolve(device); rs != RTX_OK) return rs;
 
     rtx_scene *s = new rtx_scene();
     s->device = device;
@@ -466,9 +504,36 @@ static double tile_rects(const rtx_scene *s, const rtx_params *p, DTileRects *ou
     return std::min(1.0, area / (W * H));
 }
 
+// Tile grid of the trace kernel for a frame of `rows` rows: whether the tiles are handed
+// out through queues, lanes per primary ray, tiles, entries per queue, words of the queue
+// buffer (queues + one flag byte per tile part).
+struct TilePlan {
+    bool queued;
+    uint32_t slices, tile_h, tiles, tile_seg;
+    uint64_t words;
+    DTileRects rects;
+};
+static TilePlan plan_tiles(const rtx_scene *s, const rtx_params *p, uint32_t rows) {
+    TilePlan t;
+    // Tiles through queues when the boxes leave a good part of the frame empty: only the
+    // tile parts that can hit something are traced, each by the next free wave.  Where
+    // nearly every tile has work the fixed assignment is cheaper.
+    t.queued = TRACE_QUEUE && tile_rects(s, p, &t.rects) < TRACE_QUEUE_MAX_COVER;
+    // lanes per primary ray: with queues the extra waves walk only the listed tiles
+    t.slices = (t.queued && s->trace_slices == 2) ? TRACE_SLICES_QUEUED : s->trace_slices;
+    t.tile_h = 16 / t.slices;
+    t.tiles = ((p->width + 15) / 16) * ((rows + t.tile_h - 1) / t.tile_h);
+    t.tile_seg = 4 * ((t.tiles + TILE_QUEUES - 1) / TILE_QUEUES);
+    t.words = t.queued ? (uint64_t)t.tile_seg * TILE_QUEUES + ((uint64_t)t.tiles * 4 + 3) / 4 : 0;
+    return t;
+}
+
 // Enqueue and complete one frame.  On return s->h_ctr holds the frame's counters.
+// fixed = nullptr: the scene's own work buffers, allocated and grown on demand.
+// fixed != nullptr: exactly these buffers (already sized for the frame); nothing is
+// allocated or freed, and a frame with more hit records than they hold is an error.
 static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb, hipStream_t st,
-                               rtx_stats *stats) {
+                               rtx_stats *stats, const FrameBufs *fixed = nullptr) {
     rtx_status rs = check_params(s, p);
     if (rs != RTX_OK) return rs;
     HIP_TRY(hipSetDevice(s->device));
@@ -497,30 +562,31 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     fr.scale = 1000.f / (float)p->height;
     fr.half_width = (float)p->width * 0.5f;
 
-    if (hipError_t e = grow(&s->d_first, &s->pix_cap, npix); e != hipSuccess)
-        return fail(RTX_ERR_NOMEM, std::string("pixel buffer: ") + hipGetErrorString(e));
-    if (s->rec_cap == 0) {
-        rs = ensure_records(s, std::max<uint64_t>(npix / 2, 1u << 16));
-        if (rs != RTX_OK) return rs;
+    const TilePlan plan = plan_tiles(s, p, rows);
+    const bool queued = plan.queued;
+    const uint32_t slices = plan.slices, tile_h = plan.tile_h, tiles = plan.tiles, tile_seg = plan.tile_seg;
+    const DTileRects &rects = plan.rects;
+    if (!fixed) {
+        if (hipError_t e = grow(&s->d_first, &s->pix_cap, npix); e != hipSuccess)
+            return fail(RTX_ERR_NOMEM, std::string("pixel buffer: ") + hipGetErrorString(e));
+        if (s->rec_cap == 0) {
+            // a first guess; a frame with more hits grows the buffers and is rendered again
+            rs = ensure_records(s, std::max<uint64_t>(npix / 2, 1u << 16));
+            if (rs != RTX_OK) return rs;
+        }
+        if (queued)
+            if (hipError_t e = grow(&s->d_tiles, &s->tile_cap, plan.words); e != hipSuccess)
+                return fail(RTX_ERR_NOMEM, std::string("tile queues: ") + hipGetErrorString(e));
+    }
+    FrameBufs wb;
+    if (fixed) {
+        wb = *fixed;
+    } else {
+        wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
+        wb.first = s->d_first, wb.tiles = s->d_tiles, wb.ctr = s->d_ctr;
     }
     const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
-    // Tiles through queues when the boxes leave a good part of the frame empty: only the
-    // tile parts that can hit something are traced, each by the next free wave.  Where
-    // nearly every tile has work the fixed assignment is cheaper.
-    DTileRects rects;
-    const bool queued = TRACE_QUEUE && tile_rects(s, p, &rects) < TRACE_QUEUE_MAX_COVER;
-    // lanes per primary ray: with queues the extra waves walk only the listed tiles
-    const uint32_t slices = (queued && s->trace_slices == 2) ? TRACE_SLICES_QUEUED : s->trace_slices;
-    const uint32_t tile_h = 16 / slices;
-    const uint32_t tiles = ((p->width + 15) / 16) * ((rows + tile_h - 1) / tile_h);
-    const uint32_t tile_seg = 4 * ((tiles + TILE_QUEUES - 1) / TILE_QUEUES); // entries per tile queue
-    uint8_t *d_traced = nullptr;
-    if (queued) {
-        const uint64_t words = (uint64_t)tile_seg * TILE_QUEUES + ((uint64_t)tiles * 4 + 3) / 4;
-        if (hipError_t e = grow(&s->d_tiles, &s->tile_cap, words); e != hipSuccess)
-            return fail(RTX_ERR_NOMEM, std::string("tile queues: ") + hipGetErrorString(e));
-        d_traced = reinterpret_cast<uint8_t *>(s->d_tiles + (uint64_t)tile_seg * TILE_QUEUES);
-    }
+    uint8_t *d_traced = queued ? reinterpret_cast<uint8_t *>(wb.tiles + (uint64_t)tile_seg * TILE_QUEUES) : nullptr;
     // the queue-driven shading kernels get exactly the waves that are resident at once
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
@@ -530,20 +596,20 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
 
     uint64_t n_hits = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
-        HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
+        HIP_TRY(hipMemsetAsync(wb.ctr, 0, sizeof(DCounters), st));
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
 #define LAUNCH_TRACE(SL)                                                                                     \
     do {                                                                                                     \
         if (queued) {                                                                                        \
-            tile_list_kernel<SL><<<(tiles * 4 + 255) / 256, 256, 0, st>>>(fr, rects, d_traced, s->d_tiles,   \
-                                                                         tile_seg, s->d_ctr);                \
+            tile_list_kernel<SL><<<(tiles * 4 + 255) / 256, 256, 0, st>>>(fr, rects, d_traced, wb.tiles,   \
+                                                                         tile_seg, wb.ctr);                \
             trace_kernel<SL, true><<<(uint32_t)s->n_cu * TRACE_QUEUE_BLOCKS_PER_CU, TRACE_BLOCK, 0, st>>>(   \
-                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, s->d_tiles,       \
-                tile_seg, s->d_ctr);                                                                         \
+                fr, s->d_nodes, s->n_nodes, s->d_prims, wb.recs, wb.rec_cap, wb.first, wb.tiles,       \
+                tile_seg, wb.ctr);                                                                         \
         } else {                                                                                             \
             trace_kernel<SL, false><<<std::min<uint32_t>(tiles, trace_blocks), TRACE_BLOCK, 0, st>>>(        \
-                fr, s->d_nodes, s->n_nodes, s->d_prims, s->d_recs, s->rec_cap, s->d_first, nullptr, 0,       \
-                s->d_ctr);                                                                                   \
+                fr, s->d_nodes, s->n_nodes, s->d_prims, wb.recs, wb.rec_cap, wb.first, nullptr, 0,       \
+                wb.ctr);                                                                                   \
         }                                                                                                    \
     } while (0)
         if (slices == 4)
@@ -557,19 +623,19 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     do {                                                                                                     \
         if (ieee)                                                                                            \
             shade_few_kernel<G, true><<<few_blocks, SHADE_BLOCK, 0, st>>>(                                 \
-                fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);                    \
+                fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr);                    \
         else                                                                                                 \
             shade_few_kernel<G, false><<<few_blocks, SHADE_BLOCK, 0, st>>>(                                \
-                fr, s->d_prims, s->d_mats, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);                    \
+                fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr);                    \
     } while (0)
 #define LAUNCH_SHADE(B, I)                                                                                   \
-    shade_kernel<B, I><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, s->d_recs,          \
-                                                             s->rec_cap, s->d_colors, s->d_ctr)
+    shade_kernel<B, I><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, wb.recs,          \
+                                                             wb.rec_cap, wb.colors, wb.ctr)
         const uint32_t nlg = p->n_lights;
         const bool ieee = (p->flags & RTX_FLAG_IEEE_SHADE) != 0;
         const bool few = p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
         if (!few)
-            classify_kernel<<<few_blocks, 256, 0, st>>>(fr, s->d_recs, s->rec_cap, s->d_colors, s->d_ctr);
+            classify_kernel<<<few_blocks, 256, 0, st>>>(fr, wb.recs, wb.rec_cap, wb.colors, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
         if (few) {
             // few samples: several hit records per wave
@@ -587,11 +653,11 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             else LAUNCH_SHADE(true, false);
         }
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
-        merge_kernel<<<merge_blocks, MERGE_BLOCK, (size_t)s->nest_levels * 3 * MERGE_BLOCK * sizeof(float), st>>>(fr, s->d_nodes, s->d_up, s->d_recs,
-                                                          s->d_colors, s->d_first, d_traced, tile_h, d_rgb);
+        merge_kernel<<<merge_blocks, MERGE_BLOCK, (size_t)s->nest_levels * 3 * MERGE_BLOCK * sizeof(float), st>>>(fr, s->d_nodes, s->d_up, wb.recs,
+                                                          wb.colors, wb.first, d_traced, tile_h, d_rgb);
         if (timing) HIP_TRY(hipEventRecord(s->ev[3], st));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, offsetof(DCounters, head), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s->h_ctr, wb.ctr, offsetof(DCounters, head), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         uint32_t fullest = 0;
         n_hits = 0;
@@ -599,11 +665,18 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             fullest = std::max(fullest, s->h_ctr->shard[k].count);
             n_hits += s->h_ctr->shard[k].count;
         }
-        if (fullest <= s->rec_cap / REC_SHARDS) break;
-        // a shard got more hits than it holds: grow the record buffer and render again
+        if (fullest <= wb.rec_cap / REC_SHARDS) break;
+        // a shard got more hits than it holds
+        if (fixed)
+            return fail(RTX_ERR_LIMIT, "the frame has more hit records (" + std::to_string(n_hits) +
+                                           ") than the static work area holds for it (" +
+                                           std::to_string(wb.rec_cap) + " in " + std::to_string(REC_SHARDS) +
+                                           " equal shards); use rtx_render_device");
+        // grow the record buffer and render again
         if (attempt == 2) return fail(RTX_ERR_HIP, "record buffer overflow persisted");
         rs = ensure_records(s, ((uint64_t)fullest + fullest / 8 + 128) * REC_SHARDS);
         if (rs != RTX_OK) return rs;
+        wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
     }
     s->n_hits = n_hits;
     if (stats) {
@@ -625,6 +698,41 @@ extern "C" rtx_status rtx_render_device(rtx_scene *s, const rtx_params *p, void 
                                         rtx_stats *stats) {
     if (!d_rgb) return fail(RTX_ERR_INVALID, "null output");
     return render_frame(s, p, (uint8_t *)d_rgb, (hipStream_t)hip_stream, stats);
+}
+
+// Carves the device's static work area into the buffers of one frame: counters, one record
+// head per pixel, the tile queues, and records + colours + work lists from what is left.
+extern "C" rtx_status rtx_render_device_static(rtx_scene *s, const rtx_params *p, void *d_rgb, void *hip_stream,
+                                               rtx_stats *stats) {
+    if (!d_rgb) return fail(RTX_ERR_INVALID, "null output");
+    rtx_status rs = check_params(s, p);
+    if (rs != RTX_OK) return rs;
+    unsigned char *base = (s->device >= 0 && s->device < SCRATCH_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
+    if (!base) return fail(RTX_ERR_NO_DEVICE, "no static work area was resolved for the scene's device");
+    const uint32_t rows = rtx_part_rows(p);
+    const uint64_t npix = (uint64_t)rows * p->width;
+    const TilePlan plan = plan_tiles(s, p, rows);
+    auto round256 = [](uint64_t b) { return (b + 255u) & ~(uint64_t)255u; };
+    const uint64_t ctr_bytes = round256(sizeof(DCounters)), first_bytes = round256(npix * sizeof(uint32_t)),
+                   tile_bytes = round256(plan.words * sizeof(uint32_t));
+    const uint64_t per_rec = sizeof(DRec) + sizeof(float4) + N_CLASSES * sizeof(uint32_t);
+    const uint64_t fixed_bytes = ctr_bytes + first_bytes + tile_bytes;
+    const uint64_t rec_cap = fixed_bytes < STATIC_SCRATCH_BYTES
+                                 ? ((STATIC_SCRATCH_BYTES - fixed_bytes) / per_rec) & ~(uint64_t)(4 * REC_SHARDS - 1)
+                                 : 0;
+    if (rec_cap < RTX_STATIC_MIN_RECORDS)
+        return fail(RTX_ERR_LIMIT, "frame too large for the static work area: " + std::to_string(npix) +
+                                       " pixels leave room for " + std::to_string(rec_cap) + " hit records of " +
+                                       std::to_string((uint64_t)STATIC_SCRATCH_BYTES) +
+                                       " bytes (fewer than RTX_STATIC_MIN_RECORDS); use rtx_render_device");
+    FrameBufs B;
+    B.ctr = reinterpret_cast<DCounters *>(base);
+    B.first = reinterpret_cast<uint32_t *>(base + ctr_bytes);
+    B.tiles = reinterpret_cast<uint32_t *>(base + ctr_bytes + first_bytes);
+    B.recs = reinterpret_cast<DRec *>(base + fixed_bytes);
+    B.rec_cap = (uint32_t)std::min<uint64_t>(rec_cap, 0xFFFFFFF0u & ~(uint32_t)(4 * REC_SHARDS - 1));
+    B.colors = reinterpret_cast<float4 *>(base + fixed_bytes + (uint64_t)B.rec_cap * sizeof(DRec));
+    return render_frame(s, p, (uint8_t *)d_rgb, (hipStream_t)hip_stream, stats, &B);
 }
 
 static rtx_status render_to_staging(rtx_scene *s, const rtx_params *p, rtx_stats *stats) {

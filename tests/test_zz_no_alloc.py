@@ -1,0 +1,129 @@
+"""rtx_render_device_static (the entry point that allocates nothing: every work buffer of a
+frame comes from the library's static device array) against rtx_render_device, through
+the C ABI.  Same kernels, same inputs: the output bytes and the counters must be equal.
+Two calls in a row, the second on a smaller frame (the array keeps the first call's
+contents), then the documented limits."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class DeviceBytes:
+    """Output buffer in device memory for the test, from the HIP runtime the render library
+    itself is linked against (by its soname, so that the process keeps a single copy of the
+    runtime whatever was imported before)."""
+    _hip = None
+
+    def __init__(self, n, fill):
+        if DeviceBytes._hip is None:
+            DeviceBytes._hip = C.CDLL("libamdhip64.so.7")
+        self.n, self.ptr = n, C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(n, 1))) == 0
+        assert self._hip.hipMemset(self.ptr, C.c_int(fill), C.c_size_t(n)) == 0
+
+    def numpy(self, shape):
+        assert self._hip.hipDeviceSynchronize() == 0
+        out = np.empty(shape, np.uint8)
+        assert out.nbytes == self.n
+        assert self._hip.hipMemcpy(C.c_void_p(out.ctypes.data), self.ptr, C.c_size_t(self.n), C.c_int(2)) == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+def _render_pair(sc, p):
+    """The frame through both entry points (null stream), outputs left in device memory."""
+    shape = (sc_rows(p), p.width, 3)
+    n = shape[0] * shape[1] * 3
+    out_a, out_b = DeviceBytes(n, 77), DeviceBytes(n, 99)
+    st_a = sc.render_device(p, out_a.ptr.value, 0)
+    st_b = sc.render_device_static(p, out_b.ptr.value, 0)
+    a, b = out_a.numpy(shape), out_b.numpy(shape)
+    out_a.free()
+    out_b.free()
+    return a, st_a, b, st_b
+
+
+def sc_rows(p):
+    return importlib.import_module("ray-tracing_amd").part_rows(p)
+
+
+def _same_stats(a, b):
+    for k in ("primary_rays", "hits", "shadow_rays", "shadow_tests", "lit_samples", "shadow_tests_run"):
+        assert getattr(a, k) == getattr(b, k), k
+
+
+def test_static_entry_point_equals_render_device(op, capi, scenes, rtx):
+    b = op.OracleBuilder(10)
+    d = scenes.assemble(b, "default")
+    sc = rtx.Scene(d)
+    # first call: tiles in fixed order (the boxes cover much of a square frame), 150 samples
+    # (wave-per-record kernel with sorted samples); second call, smaller: fewer pixels and
+    # records than the first left behind in the array, few-samples kernel
+    frames = [(640, 640, 150, 3), (200, 120, 5, 4)]
+    for w, h, nl, seed in frames:
+        p = capi.default_params(w, h, nl, seed)
+        rgb_a, st_a, rgb_b, st_b = _render_pair(sc, p)
+        assert st_a.hits > 1000
+        _same_stats(st_a, st_b)
+        assert np.array_equal(rgb_a, rgb_b)
+        # and both are the frame of the oracle (the bar of the other parity tests)
+        rgb_c, _, _, st_c = op.render(d, p, want_hits=False)
+        diff = np.abs(rgb_b.astype(np.int32) - rgb_c.astype(np.int32)).max(axis=2)
+        assert float((diff <= 1).mean()) >= 0.999
+        assert st_b.lit_samples == st_c.shaded_samples
+    sc.close()
+
+
+def test_static_entry_point_tile_queues_and_parts(op, capi, scenes, rtx):
+    """A frame whose tiles go through the queues (the mesh covers little of it), rendered as
+    one part of a row-striped frame, then a smaller whole frame with mirror bounces."""
+    b = op.OracleBuilder(10)
+    d = scenes.assemble(b, "bunny")
+    sc = rtx.Scene(d)
+    p = capi.default_params(1920, 1080, 100, 1)
+    p.stripe_rows, p.n_parts, p.part = 8, 2, 1
+    rgb_a, st_a, rgb_b, st_b = _render_pair(sc, p)
+    _same_stats(st_a, st_b)
+    assert st_a.hits > 10000 and np.array_equal(rgb_a, rgb_b)
+    q = capi.default_params(320, 200, 40, 2)
+    q.max_depth = 2
+    rgb_a, st_a, rgb_b, st_b = _render_pair(sc, q)
+    _same_stats(st_a, st_b)
+    assert st_a.hits > 1000 and np.array_equal(rgb_a, rgb_b)
+    sc.close()
+
+
+def test_static_entry_point_limits(op, capi, scenes, rtx):
+    """Sizes beyond the static array are refused with RTX_ERR_LIMIT and a message; the
+    allocating entry point still renders them."""
+    b = op.OracleBuilder(10)
+    d = scenes.assemble(b, "spheres")           # every pixel hits the walls
+    sc = rtx.Scene(d)
+    # 4 bytes per pixel alone exceed the 64 MiB array (refused before anything is written)
+    p = capi.default_params(8192, 4096, 1, 1)
+    out = DeviceBytes(2048 * 1024 * 3, 0)
+    with pytest.raises(rtx.RtxError) as e:
+        sc.render_device_static(p, out.ptr.value, 0)
+    assert e.value.status == 5 and "static work area" in str(e.value)
+    # the pixels fit, the hit records (one per pixel and more) do not
+    p = capi.default_params(2048, 1024, 1, 1)
+    with pytest.raises(rtx.RtxError) as e:
+        sc.render_device_static(p, out.ptr.value, 0)
+    assert e.value.status == 5 and "hit records" in str(e.value)
+    st = sc.render_device(p, out.ptr.value, 0)
+    assert st.hits >= 2048 * 1024
+    out.free()
+    # a frame that fits still renders after the refusals
+    p = capi.default_params(300, 300, 2, 1)
+    rgb_a, st_a, rgb_b, st_b = _render_pair(sc, p)
+    _same_stats(st_a, st_b)
+    assert np.array_equal(rgb_a, rgb_b)
+    sc.close()
