@@ -148,6 +148,12 @@ typedef struct rtx_params {
                                     samples by light cell.  Same hits and occlusion decisions;
                                     colours differ by the order of the per-sample sum. */
 
+#define RTX_FLAG_NO_SCREEN 16u    /* test every primitive of the leaf for every shadow ray, as the
+                                    reference does (intersect.h:99-117), instead of first ruling
+                                    out, per hit record, the triangles no shadow ray of the record
+                                    can reach.  For testing: lit-sample counts and colours must not
+                                    depend on it.  Several times slower. */
+
 /*
  * One (pixel, leaf) hit: the nearest primitive a primary ray hits inside one
  * leaf box, i.e. one successful intersect_scene call of trace_ray

@@ -13,6 +13,7 @@ RTX_FLAG_TIMING = 1
 RTX_FLAG_WAVE_PER_HIT = 2
 RTX_FLAG_IEEE_SHADE = 4
 RTX_FLAG_NO_SORT = 8
+RTX_FLAG_NO_SCREEN = 16
 
 STATUS_NAMES = {0: "RTX_OK", 1: "RTX_ERR_INVALID", 2: "RTX_ERR_NO_DEVICE", 3: "RTX_ERR_HIP",
                 4: "RTX_ERR_NOMEM", 5: "RTX_ERR_LIMIT"}

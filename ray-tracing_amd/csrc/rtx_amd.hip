@@ -105,6 +105,7 @@ struct rtx_scene {
     uint32_t nest_levels = 1; // deepest nesting of a box + 1
     uint32_t wide_dets = 0;   // some triangle's |e1| |e2| is not below the bound of rcp2_exact's range
     uint32_t trace_slices = 1; // lanes per primary ray in trace_kernel (1 or 2)
+    float coord_max = 0.f;     // largest |coordinate| of any primitive (sphere: centre +- radius)
     rtx_light light{};
     // per-frame work buffers, grown on demand
     DRec *d_recs = nullptr;
@@ -299,6 +300,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     // DET_BOUND no determinant can reach RCP2_MAX and the intersection kernels skip that check.
     const double DET_BOUND = 1.0e17;
     uint32_t wide_dets = 0;
+    double coord_max = 0.0;
     std::vector<DPrim> prims(desc->n_prims);
     for (uint32_t k = 0; k < desc->n_prims; k++) {
         const rtx_prim &p = desc->prims[k];
@@ -327,11 +329,20 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
             const double l1 = sqrt((double)e1x * e1x + (double)e1y * e1y + (double)e1z * e1z);
             const double l2 = sqrt((double)e2x * e2x + (double)e2y * e2y + (double)e2z * e2z);
             if (!(l1 * l2 < DET_BOUND)) wide_dets = 1;
+            // for the candidate screens: |e1| |e2| / |e1 x e2| and |e1| + |e2|, rounded up
+            const double ccx = (double)e1y * e2z - (double)e1z * e2y, ccy = (double)e1z * e2x - (double)e1x * e2z,
+                         ccz = (double)e1x * e2y - (double)e1y * e2x;
+            const double area2 = sqrt(ccx * ccx + ccy * ccy + ccz * ccz);
+            const double shape = l1 * l2 / area2;
+            o.shape = (area2 > 0.0 && shape < 1.0e38) ? nextafterf((float)shape, INFINITY) : 3.0e38f;
+            o.ell = (l1 + l2 < 1.0e38) ? nextafterf((float)(l1 + l2), INFINITY) : 3.0e38f;
+            for (int c = 0; c < 9; c++) coord_max = std::max(coord_max, (double)fabsf(p.g[c]));
         } else {
             o.a = host_f3(p.g);
             volatile float r2 = p.g[3] * p.g[3];
             o.b.x = p.g[3];
             o.b.y = r2;
+            for (int c = 0; c < 3; c++) coord_max = std::max(coord_max, (double)fabsf(p.g[c]) + fabs((double)p.g[3]));
         }
     }
     std::vector<DMat> mats(std::max<uint32_t>(desc->n_materials, 1));
@@ -380,6 +391,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
         n = (nodes[n].info == RTXD_NONE) ? nodes[n].link : n + 1;
     }
     s->wide_dets = wide_dets;
+    s->coord_max = (coord_max < 3.0e38) ? (float)coord_max : 3.0e38f;
     s->trace_slices = (desc->n_leaves && desc->n_prims / desc->n_leaves >= TRACE_SLICE_MIN_LEAF) ? 2u : 1u;
     s->n_prims = desc->n_prims;
     s->n_mats = desc->n_materials;
@@ -416,6 +428,20 @@ static rtx_status check_params(const rtx_scene *s, const rtx_params *p) {
     if (p->n_parts > 1 && (p->stripe_rows == 0 || p->part >= p->n_parts))
         return fail(RTX_ERR_INVALID, "bad row tiling");
     return RTX_OK;
+}
+
+// Margin of the shading kernel's candidate screens for a frame (see shade_record.h): the
+// fixed CULL_MARGIN, raised in scenes with large coordinates so that half of it always
+// covers the rounding of the screens' own plane arithmetic (at most 2^-20 times the largest
+// coordinate in play: vertices, light rectangle, start points after all their acne steps).
+// RTX_FLAG_NO_SCREEN: a margin no triangle can exceed, i.e. every leaf primitive is tested.
+static float screen_margin(const rtx_scene *s, const rtx_params *p) {
+    if (p->flags & RTX_FLAG_NO_SCREEN) return 3.0e38f;
+    double r = std::max<double>(s->coord_max, 750.0);
+    r = std::max(r, fabs((double)s->light.position[2]));
+    r += fabs((double)p->acne) * ((double)p->n_lights + 1.0);
+    const double m = std::max<double>(CULL_MARGIN, r * (1.0 / 262144.0)); // 2^-18
+    return (m < 3.0e38) ? (float)m : 3.0e38f;
 }
 
 template <typename T>
@@ -556,6 +582,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     fr.sort_samples = (p->max_depth == 0 && p->n_lights >= SORT_MIN_LIGHTS && !(p->flags & RTX_FLAG_NO_SORT)) ? 1u : 0u;
     fr.seed = p->seed;
     fr.acne = p->acne;
+    fr.cull_margin = screen_margin(s, p);
     fr.camera = host_f3(p->camera);
     fr.light_pos = host_f3(s->light.position);
     fr.light_color = host_f3(s->light.color);

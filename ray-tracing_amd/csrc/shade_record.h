@@ -14,29 +14,55 @@
 // LDS and every lane then picks up its own.
 //
 // Candidate list.  The reference tests every primitive of the leaf for every
-// shadow ray (intersect.h:99-117).  All shadow rays of one record start within
-// n_lights * acne of the hit point and aim at the light rectangle
+// shadow ray (intersect.h:99-117).  All shadow rays of one record start on the
+// segment between the first and the last start point and aim at the light rectangle
 // [250, 750]^2 x {z_light} (raytracing.h:38-39), so they stay inside the pyramid
 // spanned by the start points and that rectangle (continued beyond it: there is
-// no far limit).  A triangle that lies outside one face of that pyramid, by a
-// margin far above any rounding, fails the exact test for every one of those
-// rays, so leaving it out cannot change a result.  The faces are the planes
-// through a start point and one edge of the rectangle; g(o, v) = det[v - o,
-// La - o, Lb - o] is affine in o and in v, so "all three vertices outside for
-// the first and the last start point" implies "the whole triangle outside for
-// every start point".  Once per record, lanes run that test over the leaf's
-// triangles (one each) and compact the survivors, in order, into LDS; the
-// sample loop then walks only those.  Leaves too large for the list are
+// no far limit).  The faces are the planes through a start point and one edge of
+// the rectangle; g(o, v) = det[v - o, La - o, Lb - o] and the face's normal are both
+// affine in o, so "all three vertices outside a face by the margin, seen from the
+// first and from the last start point" implies "the whole triangle outside that face
+// by the margin for every start point on the segment".  Once per record, lanes run
+// that test over the leaf's triangles (one each) and compact the survivors, in order,
+// into LDS; the sample loop then walks only those.  Leaves too large for the list are
 // screened in segments, once per pass.
+//
+// Why leaving a triangle out cannot change a result.  In exact arithmetic a triangle
+// outside the pyramid is missed by every ray.  The float test (intersect.h:28-67) can
+// only accept a ray that misses when its computed barycentric coordinates (u, v) land in
+// the triangle although the exact ones do not.  With eps = 2^-24, s = o - v0,
+// ell = |e1| + |e2|, shape = |e1| |e2| / |e1 x e2| and nd = |n . d| (cosine between the
+// ray and the triangle's normal), a term-by-term error analysis of the test's operations
+// gives the distance between the exact and the computed crossing point of the triangle's
+// plane:   r <= 16 eps shape (|s| + ell) / nd + 2.1 eps ell.
+// A wrongly accepted ray therefore crosses the plane within r of a point Y of the
+// triangle.  If the triangle is outside the pyramid by the margin m, |X - Y| >= m for every
+// point X of every ray, so r >= m, hence nd <= 16 eps shape (|s| + ell) / (m - 2.1 eps ell):
+// the ray runs nearly inside the triangle's plane.  The start point's distance from that
+// plane is |n . s| = t nd with t = |X - o| <= |s| + ell + r, so
+//   |n . s| <= 16 eps shape (|s| + ell) (1 + (|s| + ell) / m) + 2.1 eps ell.       (*)
+// The screens test exactly this (plane_guard, with twice the constant and m / 2 to cover
+// second-order terms, the rounding of the screens' own arithmetic and of the normalised
+// ray direction, each at most 2^-20 times the largest coordinate, which
+// rtx_scene_create / screen_margin keep below m / 2): a triangle is left out only if it
+// is outside the pyramid by the margin AND both ends of the start segment are on one side
+// of its plane, farther from it than (*).  Then no start point in between satisfies (*)
+// either, and no ray of the record is accepted by the float test.
+//
+// Start points.  Where acne_chain_delta gives the closed form, the start points are
+// exactly p0 + k * delta, k = 1 .. n_lights: the segment is exact.  Otherwise they are the
+// rounded running sum (raytracing.h:40), which leaves the straight line p0 + k * step by
+// at most half an ulp of the running value per step and component; that drift bound is
+// added to the record's margin, and a record whose drift exceeds three margins is not
+// screened at all.
 #define CAND_MAX 512
-// Margin of the candidate screens, in world units.  It has to cover what separates the
-// screens' geometry from the float arithmetic it stands for: the start points of a record
-// leave the straight segment between the first and the last by the rounding of up to
-// ~1000 additions (< 0.03 at coordinates around 1000), and the triangle test's own
-// rounding (~1e-5 as a distance).
+// Margin of the candidate screens, in world units (raised for scenes with very large
+// coordinates, see screen_margin).
 #ifndef CULL_MARGIN
 #define CULL_MARGIN 0.1f
 #endif
+#define GUARD_K 1.9073486328125e-06f    // 32 eps = 2^-19: twice the constant of (*)
+#define GUARD_ABS 9.5367431640625e-07f  // 2^-20
 
 #define PASS_SAMPLES 128 // light samples per pass: two per lane
 
@@ -128,9 +154,41 @@ __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_fi
     }
 }
 
-// True if triangle (v0, v0 + e1, v0 + e2) may be hit by a shadow ray of the record.
-__device__ __forceinline__ bool may_be_hit(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi) {
+// Wave-uniform description of a record's start segment for the plane guard (*).
+struct PlaneGuard {
+    f3 o0, o1;   // first and last start point
+    float seg;   // |o1 - o0|
+    float inv_m; // 2 / margin
+};
+__device__ __forceinline__ PlaneGuard make_guard(f3 o0, f3 o1, float margin) {
+    PlaneGuard g;
+    g.o0 = o0;
+    g.o1 = o1;
+    const f3 d = f3_sub(o1, o0);
+    g.seg = __builtin_sqrtf(f3_dot(d, d)) * 1.000001f;
+    g.inv_m = 2.f / margin;
+    return g;
+}
+// True if some start point of the record may lie so close to the plane of triangle p that
+// the float test's rounding could matter (condition (*) above, or the segment crosses the
+// plane): such a triangle must be tested whatever the pyramid says.  A NaN anywhere (a
+// degenerate triangle has no normal) gives true.
+__device__ __forceinline__ bool plane_guard(const PlaneGuard &g, const DPrim *p) {
+    const f3 v0 = p->a, n = p->n;
+    const f3 s0 = f3_sub(g.o0, v0), s1 = f3_sub(g.o1, v0);
+    const float d0 = f3_dot(n, s0), d1 = f3_dot(n, s1);
+    const float reach = __builtin_sqrtf(f3_dot(s0, s0)) * 1.000001f + g.seg + p->ell; // >= |s| + ell for every start point
+    const float thr = GUARD_K * p->shape * reach * (1.f + reach * g.inv_m) + GUARD_ABS * reach;
+    const bool clear = (d0 * d1 > 0.f) && (fminf(__builtin_fabsf(d0), __builtin_fabsf(d1)) > thr);
+    return !clear;
+}
+
+// True if triangle (v0, v0 + e1, v0 + e2) lies outside the pyramid of the record's shadow
+// rays by the margin.
+__device__ __forceinline__ bool outside_pyramid(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi,
+                                                float margin) {
     const f3 v1 = f3_add(v0, e1), v2 = f3_add(v0, e2);
+    const float lim = -margin;
     bool out = false;
 #pragma unroll 1
     for (int e = 0; e < 4; e++) {
@@ -142,21 +200,21 @@ __device__ __forceinline__ bool may_be_hit(const ShadeLds &L, f3 v0, f3 e1, f3 e
             const float d0 = pl.x * v0.x + pl.y * v0.y + pl.z * v0.z - pl.w;
             const float d1 = pl.x * v1.x + pl.y * v1.y + pl.z * v1.z - pl.w;
             const float d2 = pl.x * v2.x + pl.y * v2.y + pl.z * v2.z - pl.w;
-            both &= (d0 < -CULL_MARGIN) & (d1 < -CULL_MARGIN) & (d2 < -CULL_MARGIN);
+            both &= (d0 < lim) & (d1 < lim) & (d2 < lim);
         }
         out |= both;
     }
     // all rays move towards the light plane in z
     out |= (v0.z < z_lo) & (v1.z < z_lo) & (v2.z < z_lo);
     out |= (v0.z > z_hi) & (v1.z > z_hi) & (v2.z > z_hi);
-    return !out;
+    return out;
 }
 
 // Screens primitives [seg, seg + n) of the leaf (n <= CAND_MAX) and writes the
 // survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.
 __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
                                                       uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
-                                                      float z_hi) {
+                                                      float z_hi, float margin, const PlaneGuard &guard) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
@@ -164,7 +222,8 @@ __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *_
         if (t < n) {
             const DPrim *p = leaf_prims + seg + t;
             keep = true;
-            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) keep = may_be_hit(L, p->a, p->b, p->c, z_lo, z_hi);
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                keep = !outside_pyramid(L, p->a, p->b, p->c, z_lo, z_hi, margin) || plane_guard(guard, p);
         }
         const unsigned long long mask = __ballot(keep);
         if (keep) {
@@ -175,6 +234,26 @@ __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *_
         total += (uint32_t)__popcll(mask);
     }
     return total;
+}
+
+// Start segment and margin of a record's screens.  closed: the start points are exactly
+// p0 + k * dlt, k = 1 .. n; else they follow the rounded running sum of `step`, which
+// leaves the line p0 + k * step by at most 2^-24 of the running value per step and
+// component.  Returns the margin to screen with (3e38: do not screen this record).
+__device__ __forceinline__ float screen_segment(bool closed, f3 p0, f3 step, f3 dlt, float n, float margin,
+                                                f3 &o_first, f3 &o_last) {
+    if (closed) {
+        o_first = f3_add(p0, dlt);
+        o_last = f3_make(p0.x + n * dlt.x, p0.y + n * dlt.y, p0.z + n * dlt.z);
+        return margin;
+    }
+    o_first = p0;
+    o_last = f3_add(p0, f3_scale(step, n + 1.f));
+    const float mag = fmaxf(__builtin_fabsf(p0.x), __builtin_fabsf(o_last.x)) +
+                      fmaxf(__builtin_fabsf(p0.y), __builtin_fabsf(o_last.y)) +
+                      fmaxf(__builtin_fabsf(p0.z), __builtin_fabsf(o_last.z));
+    const float drift = (n + 1.f) * 6.0e-8f * 1.01f * mag; // 2^-24 = 5.96e-8
+    return (drift <= 3.f * margin) ? margin + drift : 3.0e38f; // (a NaN drift does not screen either)
 }
 
 // One hit record, light samples in index order: one wave, lanes over the samples.
@@ -219,12 +298,14 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
 
         // pyramid of the record's shadow rays
-        const f3 o_last = f3_add(p0, f3_scale(step, nl + 1.f));
+        f3 o_first, o_last;
+        const float margin = screen_segment(closed, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
+        const PlaneGuard guard = make_guard(o_first, o_last, margin);
         const float zl = fr.light_pos.z;
-        const float o_zmin = fminf(p0.z, o_last.z), o_zmax = fmaxf(p0.z, o_last.z);
-        const float z_lo = (zl > o_zmax) ? o_zmin - CULL_MARGIN : -3.0e38f;
-        const float z_hi = (zl < o_zmin) ? o_zmax + CULL_MARGIN : 3.0e38f;
-        setup_planes(L, lane, p0, o_last, zl);
+        const float o_zmin = fminf(o_first.z, o_last.z), o_zmax = fmaxf(o_first.z, o_last.z);
+        const float z_lo = (zl > o_zmax) ? o_zmin - margin : -3.0e38f;
+        const float z_hi = (zl < o_zmin) ? o_zmax + margin : 3.0e38f;
+        setup_planes(L, lane, o_first, o_last, zl);
         wave_lds_sync();
         // a leaf that fits the list is screened once, on the first pass
         const bool one_segment = count <= CAND_MAX;
@@ -285,7 +366,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
                     n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
-                                              z_lo, z_hi);
+                                              z_lo, z_hi, margin, guard);
                     wave_lds_sync();
                 }
                 if (n_cand == 0) continue;

@@ -286,6 +286,115 @@ def test_buddha_4k_rows_sample(op, capi, built):
     assert len(hits_g) > 1000
 
 
+def test_buddha_4k_whole_frame(op, capi, built):
+    """BASELINE.json configs[3] at full size, the whole frame against the oracle: every hit
+    record (ids, distance bits), the lit-sample count and RGB."""
+    _, d, sc = built("buddha")
+    p = capi.default_params(3840, 2160, 500, 1)
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert len(hits_c) > 250000
+    check_hits(hits_g, hits_c)
+    assert check_rgb(rgb_g, rgb_c) > 0.999
+    assert st_g.lit_samples == st_c.shaded_samples and st_g.shadow_tests == st_c.shadow_prim_tests
+
+
+def test_multi_4k_stripe_sample(op, capi, built):
+    """BASELINE.json configs[4] (bunny + dino + buddha + sphere, 3840 x 2160, 1000 samples) at
+    its true size: one 8-row stripe in every 16 against the oracle."""
+    _, d, sc = built("multi")
+    p = capi.default_params(3840, 2160, 1000, 1)
+    p.stripe_rows, p.n_parts, p.part = 8, 16, 7
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert len(hits_c) > 50000
+    check_hits(hits_g, hits_c)
+    check_rgb(rgb_g, rgb_c)
+    assert st_g.lit_samples == st_c.shaded_samples
+
+
+@pytest.mark.parametrize("cfg,w,h,nl", [
+    ("spheres", 1000, 1000, 4),            # BASELINE.json configs[0] .. [4] at full size
+    ("bunny", 1920, 1080, 100),
+    ("dino_spheres", 1920, 1080, 500),
+    ("buddha", 3840, 2160, 500),
+    ("multi", 3840, 2160, 1000),
+])
+def test_screens_change_nothing_at_full_size(capi, built, cfg, w, h, nl):
+    """RTX_FLAG_NO_SCREEN tests every leaf primitive for every shadow ray, as the reference
+    does (intersect.h:99-117).  The default path first rules out, per hit record, the
+    triangles no ray of the record can reach; every occlusion decision must be the same:
+    equal lit-sample counts for the frame, per-record colours equal up to the order of the
+    per-sample sum, identical hit records."""
+    _, d, sc = built(cfg)
+    p = capi.default_params(w, h, nl, 1)
+    rgb_s, hits_s = sc.render_hits(p)
+    _, st_s = sc.render(p)
+    q = capi.default_params(w, h, nl, 1)
+    q.flags |= capi.RTX_FLAG_NO_SCREEN
+    rgb_u, hits_u = sc.render_hits(q)
+    _, st_u = sc.render(q)
+    assert st_u.shadow_tests_run == st_u.shadow_tests == st_s.shadow_tests
+    assert st_s.shadow_tests_run <= st_u.shadow_tests_run
+    assert st_s.lit_samples == st_u.lit_samples
+    for k in ("pixel", "ordinal", "leaf", "prim"):
+        assert np.array_equal(hits_s[k], hits_u[k]), k
+    assert np.array_equal(hits_s["t"].view(np.uint32), hits_u["t"].view(np.uint32))
+    rel = np.abs(hits_s["color"] - hits_u["color"]) / (np.abs(hits_u["color"]) + 1e-2)
+    assert rel.max() < 2e-4, rel.max()
+    assert np.abs(rgb_s.astype(np.int32) - rgb_u.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("cfg,w,h,nl,acne", [
+    ("buddha", 96, 64, 5000, 0.01),        # start points drift 50 units along the normal
+    ("buddha", 160, 120, 20000, 0.001),
+    ("dino_spheres", 64, 48, 6000, 0.01),
+    ("multi", 64, 36, 4096, 0.002),
+])
+def test_many_light_samples(op, capi, built, cfg, w, h, nl, acne):
+    """Thousands of light samples per hit: the running sum of the acne offset
+    (raytracing.h:40) leaves the straight line by many ulps; the screens have to follow the
+    real start points or stand down.  Lit-sample counts must equal the oracle's."""
+    _, d, sc = built(cfg)
+    p = capi.default_params(w, h, nl, 11)
+    p.acne = acne
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert len(hits_c) > 100
+    assert st_g.lit_samples == st_c.shaded_samples
+    check_hits(hits_g, hits_c, color_tol=3e-3)
+    check_rgb(rgb_g, rgb_c)
+
+
+@pytest.mark.parametrize("position,taille,light_z", [
+    ((500.0, 500.0, -7000.0), 8000.0, 800.0),     # coordinates of ~1e4, top of the mesh inside the scene cube
+    ((3000.0, -2500.0, -6000.0), 9000.0, 900.0),
+    ((500.0, 500.0, -90000.0), 100000.0, 800.0),  # ~1e5: one ulp is 0.008 units
+])
+def test_large_coordinates(op, capi, scenes, rtx, position, taille, light_z):
+    """A mesh scaled and placed so that its coordinates reach 1e4 .. 1e5: the margin of the
+    screens has to grow with the size of an ulp.  Lit-sample counts must equal the oracle's."""
+    cfg = dict(light=dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0)),
+               boxes=[("mesh", "bunny", dict(position=position, taille=taille, material="red")),
+                      ("spheres", [scenes.SPHERE_WHITE], None)])
+    b = op.OracleBuilder(10)
+    d = scenes.assemble(b, cfg)
+    sc = rtx.Scene(d)
+    p = capi.default_params(320, 240, 200, 5)
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    assert len(hits_c) > 20000
+    assert 0 < st_c.shaded_samples < st_c.shadow_rays        # some samples are occluded
+    assert st_g.lit_samples == st_c.shaded_samples
+    check_hits(hits_g, hits_c, color_tol=3e-3)
+    check_rgb(rgb_g, rgb_c)
+    sc.close()
+
+
 def test_record_buffer_growth(op, capi, rtx, scenes):
     """A first frame with far more hits than the initial record buffer holds."""
     b = op.OracleBuilder(10)
