@@ -329,13 +329,6 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
             const double l1 = sqrt((double)e1x * e1x + (double)e1y * e1y + (double)e1z * e1z);
             const double l2 = sqrt((double)e2x * e2x + (double)e2y * e2y + (double)e2z * e2z);
             if (!(l1 * l2 < DET_BOUND)) wide_dets = 1;
-            // for the candidate screens: |e1| |e2| / |e1 x e2| and |e1| + |e2|, rounded up
-            const double ccx = (double)e1y * e2z - (double)e1z * e2y, ccy = (double)e1z * e2x - (double)e1x * e2z,
-                         ccz = (double)e1x * e2y - (double)e1y * e2x;
-            const double area2 = sqrt(ccx * ccx + ccy * ccy + ccz * ccz);
-            const double shape = l1 * l2 / area2;
-            o.shape = (area2 > 0.0 && shape < 1.0e38) ? nextafterf((float)shape, INFINITY) : 3.0e38f;
-            o.ell = (l1 + l2 < 1.0e38) ? nextafterf((float)(l1 + l2), INFINITY) : 3.0e38f;
             for (int c = 0; c < 9; c++) coord_max = std::max(coord_max, (double)fabsf(p.g[c]));
         } else {
             o.a = host_f3(p.g);

@@ -48,16 +48,11 @@ struct DLeaf {
 //   sphere:   a = centre, b.x = radius, b.y = radius * radius (intersect.h:6)
 // The derived values are computed once on the host with the reference's
 // operation order; they depend on the primitive only, not on the ray.
-// shape and ell feed the candidate screens of the shading kernel only (triangles):
-//   shape = |edge1| |edge2| / |cross(edge1, edge2)| (1 / sine of the angle between the
-//           edges; 3e38 for a degenerate triangle), rounded up
-//   ell   = |edge1| + |edge2|, rounded up
 struct __attribute__((aligned(64))) DPrim {
     f3 a, b, c, n;
     uint32_t type_mat; // type | material << 8
     uint32_t id;
-    float shape;
-    float ell;
+    uint32_t pad[2];
 };
 
 // Material with the ray-independent subexpressions of shade.h folded in.

@@ -27,42 +27,37 @@
 // into LDS; the sample loop then walks only those.  Leaves too large for the list are
 // screened in segments, once per pass.
 //
-// Why leaving a triangle out cannot change a result.  In exact arithmetic a triangle
-// outside the pyramid is missed by every ray.  The float test (intersect.h:28-67) can
-// only accept a ray that misses when its computed barycentric coordinates (u, v) land in
-// the triangle although the exact ones do not.  With eps = 2^-24, s = o - v0,
-// ell = |e1| + |e2|, shape = |e1| |e2| / |e1 x e2| and nd = |n . d| (cosine between the
-// ray and the triangle's normal), a term-by-term error analysis of the test's operations
-// gives the distance between the exact and the computed crossing point of the triangle's
-// plane:   r <= 16 eps shape (|s| + ell) / nd + 2.1 eps ell.
-// A wrongly accepted ray therefore crosses the plane within r of a point Y of the
-// triangle.  If the triangle is outside the pyramid by the margin m, |X - Y| >= m for every
-// point X of every ray, so r >= m, hence nd <= 16 eps shape (|s| + ell) / (m - 2.1 eps ell):
-// the ray runs nearly inside the triangle's plane.  The start point's distance from that
-// plane is |n . s| = t nd with t = |X - o| <= |s| + ell + r, so
-//   |n . s| <= 16 eps shape (|s| + ell) (1 + (|s| + ell) / m) + 2.1 eps ell.       (*)
-// The screens test exactly this (plane_guard, with twice the constant and m / 2 to cover
-// second-order terms, the rounding of the screens' own arithmetic and of the normalised
-// ray direction, each at most 2^-20 times the largest coordinate, which
-// rtx_scene_create / screen_margin keep below m / 2): a triangle is left out only if it
-// is outside the pyramid by the margin AND both ends of the start segment are on one side
-// of its plane, farther from it than (*).  Then no start point in between satisfies (*)
-// either, and no ray of the record is accepted by the float test.
-//
-// Start points.  Where acne_chain_delta gives the closed form, the start points are
-// exactly p0 + k * delta, k = 1 .. n_lights: the segment is exact.  Otherwise they are the
-// rounded running sum (raytracing.h:40), which leaves the straight line p0 + k * step by
-// at most half an ulp of the running value per step and component; that drift bound is
-// added to the record's margin, and a record whose drift exceeds three margins is not
-// screened at all.
+// What the margin stands for.  In exact arithmetic a triangle outside the pyramid is missed
+// by every ray of the record, whatever the margin.  The margin separates that geometry from
+// the float arithmetic it stands for:
+//  * the start points.  Where acne_chain_delta gives the closed form they are exactly
+//    p0 + k * delta, k = 1 .. n_lights, and the screens use exactly that segment.  Otherwise
+//    they are the rounded running sum (raytracing.h:40), which leaves the line p0 + k * step
+//    by at most half an ulp of the running value per step and component; that bound is
+//    added to the record's margin, and a record whose bound exceeds three margins is not
+//    screened at all (screen_segment);
+//  * the screens' own plane arithmetic and the rounding of the normalised ray direction:
+//    each at most 2^-20 times the largest coordinate in play; screen_margin() raises the
+//    margin with the scene's size so that this stays below a quarter of it;
+//  * the float test itself (intersect.h:28-67).  It can accept a ray that misses only if its
+//    computed barycentric coordinates land in the triangle although the exact ones do not.
+//    With eps = 2^-24, s = o - v0, ell = |e1| + |e2|, shape = |e1| |e2| / |e1 x e2| and
+//    nd = |n . d| (cosine between ray and triangle normal), adding up the rounding of the
+//    test's operations bounds the distance between the exact and the computed crossing
+//    point of the triangle's plane by  r <= 16 eps shape (|s| + ell) / nd + 2.1 eps ell.
+//    A wrongly accepted ray crosses the plane within r of the triangle, so a triangle that is
+//    outside the pyramid by m can only be wrongly accepted by rays with
+//    nd <= 16 eps shape (|s| + ell) / m  (about 1.5e-4, i.e. within 0.01 degrees of the
+//    triangle's own plane, at 10 units from a well-shaped triangle with m = 0.1), and then
+//    only if the rounding errors happen to add up towards the triangle.  Those rays are not
+//    covered by a proof; RTX_FLAG_NO_SCREEN runs the reference's full loop nest, and the
+//    tests require equal lit-sample counts with and without the screens.
 #define CAND_MAX 512
 // Margin of the candidate screens, in world units (raised for scenes with very large
 // coordinates, see screen_margin).
 #ifndef CULL_MARGIN
 #define CULL_MARGIN 0.1f
 #endif
-#define GUARD_K 1.9073486328125e-06f    // 32 eps = 2^-19: twice the constant of (*)
-#define GUARD_ABS 9.5367431640625e-07f  // 2^-20
 
 #define PASS_SAMPLES 128 // light samples per pass: two per lane
 
@@ -154,35 +149,6 @@ __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_fi
     }
 }
 
-// Wave-uniform description of a record's start segment for the plane guard (*).
-struct PlaneGuard {
-    f3 o0, o1;   // first and last start point
-    float seg;   // |o1 - o0|
-    float inv_m; // 2 / margin
-};
-__device__ __forceinline__ PlaneGuard make_guard(f3 o0, f3 o1, float margin) {
-    PlaneGuard g;
-    g.o0 = o0;
-    g.o1 = o1;
-    const f3 d = f3_sub(o1, o0);
-    g.seg = __builtin_sqrtf(f3_dot(d, d)) * 1.000001f;
-    g.inv_m = 2.f / margin;
-    return g;
-}
-// True if some start point of the record may lie so close to the plane of triangle p that
-// the float test's rounding could matter (condition (*) above, or the segment crosses the
-// plane): such a triangle must be tested whatever the pyramid says.  A NaN anywhere (a
-// degenerate triangle has no normal) gives true.
-__device__ __forceinline__ bool plane_guard(const PlaneGuard &g, const DPrim *p) {
-    const f3 v0 = p->a, n = p->n;
-    const f3 s0 = f3_sub(g.o0, v0), s1 = f3_sub(g.o1, v0);
-    const float d0 = f3_dot(n, s0), d1 = f3_dot(n, s1);
-    const float reach = __builtin_sqrtf(f3_dot(s0, s0)) * 1.000001f + g.seg + p->ell; // >= |s| + ell for every start point
-    const float thr = GUARD_K * p->shape * reach * (1.f + reach * g.inv_m) + GUARD_ABS * reach;
-    const bool clear = (d0 * d1 > 0.f) && (fminf(__builtin_fabsf(d0), __builtin_fabsf(d1)) > thr);
-    return !clear;
-}
-
 // True if triangle (v0, v0 + e1, v0 + e2) lies outside the pyramid of the record's shadow
 // rays by the margin.
 __device__ __forceinline__ bool outside_pyramid(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi,
@@ -214,7 +180,7 @@ __device__ __forceinline__ bool outside_pyramid(const ShadeLds &L, f3 v0, f3 e1,
 // survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.
 __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
                                                       uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
-                                                      float z_hi, float margin, const PlaneGuard &guard) {
+                                                      float z_hi, float margin) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
@@ -223,7 +189,7 @@ __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *_
             const DPrim *p = leaf_prims + seg + t;
             keep = true;
             if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                keep = !outside_pyramid(L, p->a, p->b, p->c, z_lo, z_hi, margin) || plane_guard(guard, p);
+                keep = !outside_pyramid(L, p->a, p->b, p->c, z_lo, z_hi, margin);
         }
         const unsigned long long mask = __ballot(keep);
         if (keep) {
@@ -300,7 +266,6 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         // pyramid of the record's shadow rays
         f3 o_first, o_last;
         const float margin = screen_segment(closed, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
-        const PlaneGuard guard = make_guard(o_first, o_last, margin);
         const float zl = fr.light_pos.z;
         const float o_zmin = fminf(o_first.z, o_last.z), o_zmax = fmaxf(o_first.z, o_last.z);
         const float z_lo = (zl > o_zmax) ? o_zmin - margin : -3.0e38f;
@@ -366,7 +331,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
                     n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
-                                              z_lo, z_hi, margin, guard);
+                                              z_lo, z_hi, margin);
                     wave_lds_sync();
                 }
                 if (n_cand == 0) continue;

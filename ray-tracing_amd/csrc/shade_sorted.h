@@ -160,50 +160,38 @@ __device__ __forceinline__ uint32_t cell_mask(const RayFan &f, f3 v0, f3 e1, f3 
 }
 
 // Screens the n <= CAND_MAX primitives of the leaf: offsets inside the leaf of those that
-// are not outside_fan, or that the plane guard wants tested whatever the geometry says, in
-// order, to L.cand.  The latter (and everything that is not a triangle) carry CAND_ALL_CELLS:
-// their cell mask is "every cell".  Returns how many.
-#define CAND_ALL_CELLS 0x8000u
-#define CAND_INDEX 0x7FFFu
-static_assert(CAND_MAX <= CAND_INDEX, "candidate offsets share their 16 bits with a flag");
-__device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFan &fan, const PlaneGuard &guard,
+// are not outside_fan, in order, to L.cand.  Returns how many.
+__device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFan &fan,
                                                           const DPrim *__restrict__ leaf_prims, uint32_t n,
                                                           uint32_t lane) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
         bool keep = false;
-        uint32_t all_cells = CAND_ALL_CELLS;
         if (t < n) {
             const DPrim *p = leaf_prims + t;
             keep = true;
-            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                if (!plane_guard(guard, p)) {
-                    all_cells = 0u;
-                    keep = !outside_fan(fan, p->a, p->b, p->c);
-                }
-            }
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) keep = !outside_fan(fan, p->a, p->b, p->c);
         }
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            L.cand[pos] = (uint16_t)(t | all_cells);
+            L.cand[pos] = (uint16_t)t;
         }
         total += (uint32_t)__popcll(mask);
     }
     return total;
 }
 
-// Cell masks of the n_cand candidates, to L.cells (readers of L.cand mask the flag off).
+// Cell masks of the n_cand candidates, to L.cells.
 __device__ __forceinline__ void build_cell_masks(SortLds &L, const RayFan &fan,
                                                  const DPrim *__restrict__ leaf_prims, uint32_t n_cand,
                                                  uint32_t lane) {
     for (uint32_t c = lane; c < n_cand; c += 64) {
-        const uint32_t entry = L.cand[c];
-        const DPrim *p = leaf_prims + (entry & CAND_INDEX);
+        const DPrim *p = leaf_prims + L.cand[c];
         uint32_t cells = 0xFFFFu;
-        if (!(entry & CAND_ALL_CELLS)) cells = cell_mask(fan, p->a, p->b, p->c);
+        if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) cells = cell_mask(fan, p->a, p->b, p->c);
         L.cells[c] = (uint16_t)cells;
     }
 }
@@ -219,7 +207,7 @@ __device__ __forceinline__ uint32_t filter_candidates(SortLds &L, uint32_t n_can
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            L.pass[pos] = L.cand[c] & CAND_INDEX;
+            L.pass[pos] = L.cand[c];
         }
         total += (uint32_t)__popcll(mask);
     }
@@ -318,8 +306,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             f3 o_first, o_last;
             const float margin = screen_segment(true, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
             const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
-            const PlaneGuard guard = make_guard(o_first, o_last, margin);
-            n_cand = build_fan_candidates(L, fan, guard, leaf_prims, count, lane);
+            n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane);
             use_sort = n_cand >= SORT_MIN_CAND;
             wave_lds_sync();
             if (use_sort) build_cell_masks(L, fan, leaf_prims, n_cand, lane);
@@ -381,11 +368,11 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                 bool any1 = false, any2 = false;
                 if (n_list) {
                     tests_total += (unsigned long long)n_list * min(n_chunk - base, (uint32_t)PASS_SAMPLES);
-                    uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)list[0]) & CAND_INDEX;
+                    uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)list[0]);
                     DPrim cur = leaf_prims[ci];
                     for (uint32_t c = 0; c < n_list; c++) {
                         const uint32_t cn = __builtin_amdgcn_readfirstlane(
-                            (uint32_t)list[(c + 1 < n_list) ? c + 1 : c]) & CAND_INDEX;
+                            (uint32_t)list[(c + 1 < n_list) ? c + 1 : c]);
                         const DPrim nxt = leaf_prims[cn];
                         bool ok1 = live1, ok2 = live2;
                         v2f t = (v2f){0.f, 0.f};
