@@ -698,6 +698,16 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (rs != RTX_OK) return rs;
         wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
     }
+#ifdef STEP_STATS
+    {
+        const unsigned long long *c = reinterpret_cast<const unsigned long long *>(s->h_ctr->pad1);
+        fprintf(stderr, "step stats: steps %llu  all fail u %llu  all fail u|v %llu  all fail t %llu  no hit %llu  "
+                        "clearly outside uv %llu  clearly behind %llu  clearly either %llu\n",
+                c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+        fprintf(stderr, "classes (sorted heavy, sorted light, plain heavy, plain light): %u %u %u %u; sorted records that sort %llu; plain records not closed %llu\n",
+                s->h_ctr->cls[0].count, s->h_ctr->cls[1].count, s->h_ctr->cls[2].count, s->h_ctr->cls[3].count, c[8], c[9]);
+    }
+#endif
     s->n_hits = n_hits;
     if (stats) {
         stats->primary_rays = npix;

@@ -271,11 +271,12 @@ __device__ __forceinline__ v2f div2_exact(v2f n, const recip2 &R) {
 __device__ __forceinline__ void normalize2(v2f &x, v2f &y, v2f &z) {
     const v2f dd = x * x + y * y + z * z;
     const v2f len = (v2f){__builtin_sqrtf(dd.x), __builtin_sqrtf(dd.y)};
-    const v2f ax = __builtin_elementwise_abs(x), ay = __builtin_elementwise_abs(y), az = __builtin_elementwise_abs(z);
+    // smallest |component| of each vector (a NaN component makes the norm NaN, which fails
+    // the range test on the norm, so fminf dropping NaNs loses nothing)
+    const float lo1 = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x.x), __builtin_fabsf(y.x)), __builtin_fabsf(z.x));
+    const float lo2 = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x.y), __builtin_fabsf(y.y)), __builtin_fabsf(z.y));
     const bool plain = len.x >= DIV2_DEN_MIN && len.x <= DIV2_DEN_MAX && len.y >= DIV2_DEN_MIN &&
-                       len.y <= DIV2_DEN_MAX && ax.x >= DIV2_NUM_MIN && ax.y >= DIV2_NUM_MIN &&
-                       ay.x >= DIV2_NUM_MIN && ay.y >= DIV2_NUM_MIN && az.x >= DIV2_NUM_MIN &&
-                       az.y >= DIV2_NUM_MIN;
+                       len.y <= DIV2_DEN_MAX && lo1 >= DIV2_NUM_MIN && lo2 >= DIV2_NUM_MIN;
     if (__builtin_expect(__all(plain), 1)) {
         const recip2 R = recip2_make(len);
         x = div2_exact(x, R);
@@ -425,7 +426,10 @@ __device__ __forceinline__ bool acne_chain_delta(float p0, float c, uint32_t n, 
     // into the finer grid below the edge even when it would round back to p_0 on u
     if ((bits & 0x7FFFFFu) == 0u && ((__float_as_uint(c) ^ bits) >> 31) && c != 0.f) return false;
     const float u = __uint_as_float((ex - 23u) << 23);
-    const float q = c / u; // exact: u is a power of two
+    // c / u as a product: 1 / u = 2^(150 - ex) is a normal power of two for every ex admitted
+    // above, and the correctly rounded product c * (1 / u) is the correctly rounded quotient
+    // c / u (the same real number)
+    const float q = c * __uint_as_float((277u - ex) << 23);
     if (!(__builtin_fabsf(q) * (float)(n + 1u) < 8388608.f)) return false;
     const float r = __builtin_rintf(q);
     if (__builtin_fabsf(q - r) == 0.5f) return false;

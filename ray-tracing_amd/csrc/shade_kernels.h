@@ -85,10 +85,12 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
     // short records are popped several at a time, unless the list is too short for that
     const uint32_t batch = (cls == CLASS_LIGHTEST && n >= 8u * gridDim.x * SHADE_WAVES) ? QUEUE_BATCH : 1u;
     uint32_t q = blockIdx.x % QUEUE_HEADS, moves = 0;
+    // The pop for the next turn is issued before the current records are shaded, so that the
+    // returning atomic (microseconds under contention) is in flight meanwhile.
+    uint32_t k_ahead = 0;
+    if (lane == 0) k_ahead = atomicAdd(&ctr->head[cls][q].next, batch);
     for (;;) {
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&ctr->head[cls][q].next, batch);
-        k = __builtin_amdgcn_readfirstlane(k);
+        const uint32_t k = __builtin_amdgcn_readfirstlane(k_ahead);
         if (k * QUEUE_HEADS + q >= n) {
             // This head is drained.  Look at all of them (plain loads: a failing atomic
             // per head and wave would add up) and go on with one that is not, if any; the
@@ -103,8 +105,10 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(open >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)open, 0u));
             q = (uint32_t)__ffsll((long long)__ballot(is_open && rank == pick)) - 1u;
+            if (lane == 0) k_ahead = atomicAdd(&ctr->head[cls][q].next, batch);
             continue;
         }
+        if (lane == 0) k_ahead = atomicAdd(&ctr->head[cls][q].next, batch);
         for (uint32_t kb = k; kb < k + batch; kb++) {
             const uint32_t e = kb * QUEUE_HEADS + q;
             if (e >= n) break;
@@ -149,6 +153,10 @@ void shade_kernel(
     }
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
     if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
+#ifdef STEP_STATS
+    if (lane == 0)
+        for (int k = 0; k < 10; k++) atomicAdd(reinterpret_cast<unsigned long long *>(ctr->pad1) + k, tot.st[k]);
+#endif
     if (lane == 0 && tot.bounce_hits) {
         atomicAdd(&ctr->bounce_hits, (unsigned long long)tot.bounce_hits);
         atomicAdd(&ctr->bounce_prims, tot.bounce_prims);

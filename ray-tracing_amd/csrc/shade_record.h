@@ -228,7 +228,46 @@ __device__ __forceinline__ float screen_segment(bool closed, f3 p0, f3 step, f3 
 struct ShadeTotals {
     uint32_t lit = 0, bounce_hits = 0;
     unsigned long long tests = 0, bounce_prims = 0;
+#ifdef STEP_STATS
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 };
+#ifdef STEP_STATS
+// (measurement build only) why the rays of one candidate step fail
+__device__ __forceinline__ void step_stats(ShadeTotals &tot, const ray2 &r, const DPrim &p, bool live1, bool live2) {
+    if ((p.type_mat & 0xFFu) != RTX_PRIM_TRIANGLE) return;
+    uint32_t why[2];
+    for (int k = 0; k < 2; k++) {
+        const f3 o = f3_make(r.ox[k], r.oy[k], r.oz[k]), d = f3_make(r.dx[k], r.dy[k], r.dz[k]);
+        const f3 h = f3_cross(d, p.c);
+        const float a = f3_dot(p.b, h), f = 1.f / a;
+        const f3 s = f3_sub(o, p.a);
+        const float u = f * f3_dot(s, h);
+        const f3 q = f3_cross(s, p.b);
+        const float v = f * f3_dot(d, q), t = f * f3_dot(p.c, q);
+        why[k] = ((u < 0.f || u > 1.f) ? 1u : 0u) | ((v < 0.f || u + v > 1.f) ? 2u : 0u) | (!(t > 1e-7f) ? 4u : 0u);
+        // 8: fails u or v by a clear margin; 16: behind by a clear margin
+        why[k] |= ((u < -0.01f || u > 1.01f || v < -0.01f || u + v > 1.01f) ? 8u : 0u) | ((t < -1e-3f) ? 16u : 0u);
+    }
+    if (!live1) why[0] = 31u;
+    if (!live2) why[1] = 31u;
+    const bool all_u = __all((why[0] & 1u) && (why[1] & 1u));
+    const bool all_uv = __all((why[0] & 3u) && (why[1] & 3u));
+    const bool all_t = __all((why[0] & 4u) && (why[1] & 4u));
+    const bool none = __all(why[0] && why[1]);
+    const bool clear_uv = __all((why[0] & 8u) && (why[1] & 8u));
+    const bool clear_t = __all((why[0] & 16u) && (why[1] & 16u));
+    const bool clear_any = __all((why[0] & 24u) && (why[1] & 24u));
+    tot.st[0]++;
+    tot.st[1] += all_u;
+    tot.st[2] += all_uv;
+    tot.st[3] += all_t;
+    tot.st[4] += none;
+    tot.st[5] += clear_uv;
+    tot.st[6] += clear_t;
+    tot.st[7] += clear_any;
+}
+#endif
 
 template <bool BOUNCE, bool IEEE>
 __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__restrict__ prims,
@@ -260,6 +299,9 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const bool cy = acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
         const bool cz = acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
         const bool closed = cx && cy && cz;
+#ifdef STEP_STATS
+        tot.st[9] += !closed;
+#endif
         float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
 
@@ -345,6 +387,9 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                     const DPrim nxt = leaf_prims[seg + cn];
                     bool ok1 = live1, ok2 = live2;
                     v2f t = (v2f){0.f, 0.f};
+#ifdef STEP_STATS
+                    step_stats(tot, rr, cur, live1, live2);
+#endif
                     if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
                         tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
                     } else {

@@ -308,6 +308,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
             n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane);
             use_sort = n_cand >= SORT_MIN_CAND;
+#ifdef STEP_STATS
+            tot.st[8] += use_sort;
+#endif
             wave_lds_sync();
             if (use_sort) build_cell_masks(L, fan, leaf_prims, n_cand, lane);
         }
@@ -376,6 +379,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                         const DPrim nxt = leaf_prims[cn];
                         bool ok1 = live1, ok2 = live2;
                         v2f t = (v2f){0.f, 0.f};
+#ifdef STEP_STATS
+                        step_stats(tot, rr, cur, live1, live2);
+#endif
                         if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
                             tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
                         } else {
