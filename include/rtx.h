@@ -258,6 +258,13 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
 rtx_status rtx_render_device_static(rtx_scene *scene, const rtx_params *p, void *d_rgb,
                                     void *hip_stream, rtx_stats *stats);
 
+/* Page-locked host memory for rgb_host: rtx_render copies a frame into such a buffer
+ * at the full rate of the link; into ordinary memory it runs at roughly half of it.  No
+ * counterpart in the reference (its frame lives in a FreeImage bitmap,
+ * raytracing.h:105). */
+rtx_status rtx_host_alloc(uint64_t bytes, void **out);
+void rtx_host_free(void *p);
+
 /* Render and also return the per-(pixel, leaf) hit records, sorted by
  * (pixel, ordinal).  At most `capacity` records are written; *n_hits receives
  * the number found.  rgb_host may be NULL. */

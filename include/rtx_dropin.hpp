@@ -128,6 +128,16 @@ bool flatten(const Light &light, const Boxs &boxs, int box_depth, FlatScene &out
 bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t> &rgb,
                       rtx_stats *stats, std::string *error);
 
+// render_image / render_to_memory keep what they uploaded: one scene replica per entry of
+// settings().devices (or one on settings().device), reused by later calls as long as the
+// flattened scene has the same content, so that a caller rendering the same `Boxs` again
+// (other frame size, sample count, camera ...) pays neither the conversion to the device
+// layout nor the upload again.  created / reused count replicas since the process started;
+// release_replicas() frees them (call it before the process ends if the HIP runtime must
+// see every free).
+void replica_stats(uint64_t *created, uint64_t *reused);
+void release_replicas();
+
 // Minimal PNG (8-bit RGB, stored deflate blocks) and PPM writers.  Row j = 0 of `rgb`
 // is written as the BOTTOM scanline, as FreeImage_SetPixelColor places it
 // (raytracing.h:130).

@@ -784,6 +784,22 @@ extern "C" rtx_status rtx_render(rtx_scene *s, const rtx_params *p, uint8_t *rgb
     return RTX_OK;
 }
 
+extern "C" rtx_status rtx_host_alloc(uint64_t bytes, void **out) {
+    if (!out) return fail(RTX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (rtx_device_count() <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(RTX_ERR_NOMEM, std::string("page-locked host memory: ") + hipGetErrorString(e));
+    }
+    return RTX_OK;
+}
+
+extern "C" void rtx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" rtx_status rtx_render_hits(rtx_scene *s, const rtx_params *p, rtx_hit *hits, uint64_t capacity,
                                       uint64_t *n_hits, uint8_t *rgb_host) {
     if (!n_hits) return fail(RTX_ERR_INVALID, "null n_hits");

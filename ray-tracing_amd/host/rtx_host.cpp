@@ -359,15 +359,77 @@ bool flatten(const Light &light, const Boxs &boxs, int box_depth, FlatScene &out
 // ---------------------------------------------------------------------------------------
 // rendering
 // ---------------------------------------------------------------------------------------
-// One part of the frame on one device (synchronous).  Returns "" or an error message.
-static std::string render_part(const rtx_scene_desc &d, int device, const rtx_params &p, uint8_t *out,
-                               rtx_stats *stats) {
+// Scene replicas kept between calls (see rtx_dropin.hpp).  The caller is single-threaded,
+// as the reference's main() is; the worker threads below each touch only their own slot.
+namespace {
+
+struct Replica {
     rtx_scene *scene = nullptr;
-    if (rtx_scene_create(&d, device, &scene) != RTX_OK) return rtx_last_error();
-    std::string err;
-    if (rtx_render(scene, &p, out, stats) != RTX_OK) err = rtx_last_error();
-    rtx_scene_destroy(scene);
-    return err;
+    int device = -1;
+    uint8_t *staging = nullptr; // page-locked, for the packed rows of this replica's part
+    size_t staging_bytes = 0;
+};
+
+struct ReplicaCache {
+    uint64_t key = 0;
+    size_t sizes[4] = {0, 0, 0, 0};
+    bool valid = false;
+    std::vector<Replica> slots;
+    uint64_t created = 0, reused = 0;
+} g_replicas;
+
+uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+
+uint64_t content_key(const FlatScene &f) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv1a(h, f.nodes.data(), f.nodes.size() * sizeof(rtx_node));
+    h = fnv1a(h, f.leaves.data(), f.leaves.size() * sizeof(rtx_leaf));
+    h = fnv1a(h, f.prims.data(), f.prims.size() * sizeof(rtx_prim));
+    h = fnv1a(h, f.materials.data(), f.materials.size() * sizeof(rtx_material));
+    return fnv1a(h, &f.light, sizeof(f.light));
+}
+
+void free_slot(Replica &r) {
+    if (r.scene) rtx_scene_destroy(r.scene);
+    if (r.staging) rtx_host_free(r.staging);
+    r = Replica();
+}
+
+// The replica of slot k on `device` for the scene `d`; uploads it if the slot is empty or
+// holds another device's.  Returns "" or an error message.
+std::string get_replica(size_t k, int device, const rtx_scene_desc &d, Replica **out) {
+    if (g_replicas.slots.size() <= k) g_replicas.slots.resize(k + 1);
+    Replica &r = g_replicas.slots[k];
+    if (r.scene && r.device != device) free_slot(r);
+    if (!r.scene) {
+        if (rtx_scene_create(&d, device, &r.scene) != RTX_OK) {
+            r.scene = nullptr;
+            return rtx_last_error();
+        }
+        r.device = device;
+        g_replicas.created++;
+    } else {
+        g_replicas.reused++;
+    }
+    *out = &r;
+    return "";
+}
+
+} // namespace
+
+void replica_stats(uint64_t *created, uint64_t *reused) {
+    if (created) *created = g_replicas.created;
+    if (reused) *reused = g_replicas.reused;
+}
+
+void release_replicas() {
+    for (Replica &r : g_replicas.slots) free_slot(r);
+    g_replicas.slots.clear();
+    g_replicas.valid = false;
 }
 
 bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t> &rgb, rtx_stats *stats,
@@ -376,21 +438,41 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
     FlatScene flat;
     if (!flatten(light, boxs, cfg.box_depth, flat, error)) return false;
     const rtx_scene_desc d = flat.desc();
+    // another scene than last time: the replicas are of no use any more
+    const uint64_t key = content_key(flat);
+    const size_t sizes[4] = {flat.nodes.size(), flat.leaves.size(), flat.prims.size(), flat.materials.size()};
+    if (!g_replicas.valid || g_replicas.key != key || std::memcmp(sizes, g_replicas.sizes, sizeof(sizes)) != 0) {
+        release_replicas();
+        g_replicas.key = key;
+        std::memcpy(g_replicas.sizes, sizes, sizeof(sizes));
+        g_replicas.valid = true;
+    }
     rtx_params p = cfg.frame;
     p.stripe_rows = p.n_parts = p.part = 0;
     rgb.assign((size_t)p.width * p.height * 3, 0);
     if (cfg.devices.size() <= 1) {
-        const std::string err = render_part(d, cfg.devices.empty() ? cfg.device : cfg.devices[0], p, rgb.data(), stats);
+        Replica *r = nullptr;
+        std::string err = get_replica(0, cfg.devices.empty() ? cfg.device : cfg.devices[0], d, &r);
+        if (err.empty() && rtx_render(r->scene, &p, rgb.data(), stats) != RTX_OK) err = rtx_last_error();
         if (!err.empty() && error) *error = err;
         return err.empty();
     }
     // Row stripes dealt round-robin to the devices: stripe s goes to part s % n_parts.
-    // Every part renders into a packed buffer of its own rows; the rows are then copied
-    // to their place in the frame.  The sampler is keyed by the global pixel index, so
-    // the frame does not depend on the split.
+    // Every part renders its rows, packed, into page-locked memory of its own and its host
+    // thread then copies them to their place in the frame (the parts' rows are disjoint).
+    // The sampler is keyed by the global pixel index, so the frame does not depend on the
+    // split.
     const uint32_t parts = (uint32_t)cfg.devices.size();
     const uint32_t stripe = cfg.stripe_rows ? cfg.stripe_rows : 8;
-    std::vector<std::vector<uint8_t>> tiles(parts);
+    std::vector<Replica *> replica(parts, nullptr);
+    if (g_replicas.slots.size() < parts) g_replicas.slots.resize(parts); // (before any pointer into it is taken)
+    for (uint32_t k = 0; k < parts; k++) { // (uploads happen here, on the caller's thread)
+        const std::string err = get_replica(k, cfg.devices[k], d, &replica[k]);
+        if (!err.empty()) {
+            if (error) *error = err;
+            return false;
+        }
+    }
     std::vector<std::string> errors(parts);
     std::vector<rtx_stats> part_stats(parts);
     std::vector<std::thread> workers;
@@ -400,8 +482,31 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
             q.stripe_rows = stripe;
             q.n_parts = parts;
             q.part = k;
-            tiles[k].resize((size_t)rtx_part_rows(&q) * q.width * 3);
-            errors[k] = render_part(d, cfg.devices[k], q, tiles[k].data(), &part_stats[k]);
+            Replica &r = *replica[k];
+            const size_t row_bytes = (size_t)q.width * 3, need = (size_t)rtx_part_rows(&q) * row_bytes;
+            if (need == 0) return;
+            if (r.staging_bytes < need) {
+                if (r.staging) rtx_host_free(r.staging);
+                r.staging = nullptr;
+                r.staging_bytes = 0;
+                void *mem = nullptr;
+                if (rtx_host_alloc(need, &mem) != RTX_OK) {
+                    errors[k] = rtx_last_error();
+                    return;
+                }
+                r.staging = static_cast<uint8_t *>(mem);
+                r.staging_bytes = need;
+            }
+            if (rtx_render(r.scene, &q, r.staging, &part_stats[k]) != RTX_OK) {
+                errors[k] = rtx_last_error();
+                return;
+            }
+            size_t src = 0;
+            for (uint32_t j0 = k * stripe; j0 < q.height; j0 += parts * stripe) { // this part's stripes
+                const size_t rows = std::min<uint32_t>(stripe, q.height - j0);
+                std::memcpy(rgb.data() + (size_t)j0 * row_bytes, r.staging + src, rows * row_bytes);
+                src += rows * row_bytes;
+            }
         });
     }
     for (std::thread &t : workers) t.join();
@@ -410,13 +515,6 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
         if (!errors[k].empty()) {
             if (error) *error = errors[k];
             return false;
-        }
-        const size_t row_bytes = (size_t)p.width * 3;
-        size_t src = 0;
-        for (uint32_t j = 0; j < p.height; j++) {
-            if ((j / stripe) % parts != k) continue;
-            std::memcpy(rgb.data() + (size_t)j * row_bytes, tiles[k].data() + src, row_bytes);
-            src += row_bytes;
         }
         if (stats) {
             stats->primary_rays += part_stats[k].primary_rays;
@@ -540,11 +638,14 @@ bool render_image(Light &light, Boxs &boxs) {
         std::fprintf(stderr, "render_image: %s\n", error.c_str());
         return false;
     }
+    // raytracing.h:132-135 prints "Rendering image... N %" after every tenth row; here the
+    // rows arrive all at once
     if (!cfg.quiet) std::printf("Rendering image... 100 %%\r");
     const std::string &path = cfg.output;
     const bool ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
     const bool saved = ppm ? rtx_host::write_ppm(path, rgb.data(), cfg.frame.width, cfg.frame.height)
                            : rtx_host::write_png(path, rgb.data(), cfg.frame.width, cfg.frame.height);
     if (saved && !cfg.quiet) std::printf("\nImage successfully saved!\n"); // raytracing.h:141
-    return true;
+    if (!saved) std::fprintf(stderr, "render_image: cannot write %s\n", path.c_str());
+    return saved;
 }

@@ -163,6 +163,13 @@ int rtxh_render_image(void *h, const rtx_params *p, const int *devices, uint32_t
     return render_image(b->light, b->boxs) ? 0 : 1;
 }
 
+// created / reused scene replicas of render_image since the process started; release != 0
+// also frees the replicas it keeps.
+void rtxh_replica_stats(uint64_t out[2], int release) {
+    rtx_host::replica_stats(&out[0], &out[1]);
+    if (release) rtx_host::release_replicas();
+}
+
 int rtxh_write_png(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h) {
     return rtx_host::write_png(path, rgb, w, h) ? 0 : 1;
 }

@@ -36,6 +36,7 @@ def lib():
         L.rtxh_render_image.argtypes = [C.c_void_p, C.POINTER(capi.Params), C.POINTER(C.c_int), C.c_uint32,
                                         C.c_char_p]
         L.rtxh_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rtxh_replica_stats.argtypes = [C.c_uint64 * 2, C.c_int]
         _lib = L
     return _lib
 
@@ -101,6 +102,14 @@ class HostBuilder:
             self.close()
         except Exception:
             pass
+
+
+def replica_stats(release=False):
+    """(created, reused) scene replicas of render_image since the process started;
+    release=True also frees the replicas it keeps between calls."""
+    out = (C.c_uint64 * 2)()
+    lib().rtxh_replica_stats(out, 1 if release else 0)
+    return int(out[0]), int(out[1])
 
 
 def parse_off(path):

@@ -486,7 +486,7 @@ def test_limits_are_errors(capi, rtx, built):
         sc.render(p)
 
 
-def test_render_image_drop_in(op, capi, scenes, built, tmp_path):
+def test_render_image_drop_in(op, capi, scenes, rtx, built, tmp_path):
     """render_image() of the C++ host layer (raytracing.h:100): builds the scene with
     create_mesh / create_boxs, renders on the GPU and writes the PNG; the decoded file
     must be the frame the C ABI returns for the oracle-built description."""
@@ -514,9 +514,26 @@ def test_render_image_drop_in(op, capi, scenes, built, tmp_path):
     check_rgb(img, rgb_c)
     # the same frame split into row stripes over three scene replicas (three host threads;
     # on a one-GPU box all on device 0): the assembled file must be identical
+    created0, reused0 = host.replica_stats()
     path3 = str(tmp_path / "out3.png")
     hb.render_image(p, path3, devices=(0, 0, 0))
     assert open(path3, "rb").read() == data
+    # the replicas are kept: the same scene again (other sample count) uploads nothing, and
+    # one stripe per visible device gives the same file as one device
+    created1, reused1 = host.replica_stats()
+    assert created1 - created0 == 2 and reused1 - reused0 == 1     # slot 0 was there already
+    q = capi.default_params(300, 200, 9, 4)
+    n_dev = max(1, rtx.device_count())
+    hb.render_image(q, str(tmp_path / "a.png"), devices=tuple(range(n_dev)) * (3 if n_dev == 1 else 1))
+    created2, reused2 = host.replica_stats()
+    if n_dev == 1:
+        assert created2 == created1 and reused2 - reused1 == 3
+    hb.render_image(q, str(tmp_path / "b.png"), devices=(0,))
+    assert open(str(tmp_path / "a.png"), "rb").read() == open(str(tmp_path / "b.png"), "rb").read()
+    # a file that cannot be written is a failure of render_image (raytracing.h:140-142)
+    with pytest.raises(RuntimeError):
+        hb.render_image(q, str(tmp_path / "no_such_dir" / "c.png"))
+    host.replica_stats(release=True)
 
 
 @pytest.mark.parametrize("cfg,camera", [

@@ -138,3 +138,63 @@ def test_reference_main_builds_against_the_drop_in(tmp_path):
            "-L", os.path.join(root, "ray-tracing_amd", "host"), "-lrtx_host",
            "-L", os.path.join(root, "ray-tracing_amd", "csrc"), "-lrtx_amd"]
     subprocess.check_call(cmd)
+
+
+def _mesh_dir(scenes, where):
+    os.makedirs(os.path.join(where, "meshs"))
+    for name in ("bunny", "dino"):
+        v, f = scenes.load_mesh(name)
+        _write_off(os.path.join(where, "meshs", name + ".off"), v, f)
+
+
+RT_MAIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray-tracing_amd", "host",
+                       "rt_main")
+
+
+def test_rt_main_prints_what_main_cpp_prints(scenes, rtx, tmp_path):
+    """The command-line renderer's text follows main.cpp:9-31: banner, start time and the
+    first progress line before the frame.  Without a GPU the render step then fails loudly
+    (exit code 1, message on stderr, no 'Finish time'); the complete text is checked by the
+    GPU test below."""
+    import re
+    import subprocess
+    _mesh_dir(scenes, str(tmp_path))
+    out = subprocess.run([RT_MAIN, "--width", "64", "--height", "48", "--lights", "2"], cwd=str(tmp_path),
+                         capture_output=True, timeout=300)
+    head = r"RAY TRACING by Romain Roy\n-------------------------\nStart time: \d+:\d+:\d+\nRendering image\.\.\. 0 %\r"
+    assert re.match(head, out.stdout.decode()), out.stdout
+    if rtx.device_count() == 0:
+        assert out.returncode == 1 and b"render_image:" in out.stderr and b"Finish time" not in out.stdout
+    # a scene file that is not an OFF file ends the program before anything is rendered
+    (tmp_path / "meshs" / "dino.off").write_text("PLY\n")
+    out = subprocess.run([RT_MAIN], cwd=str(tmp_path), capture_output=True, timeout=300)
+    assert out.returncode == 1 and b"Start time" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_rt_main_renders_and_reports(scenes, tmp_path):
+    """main.cpp:9-31 and raytracing.h:132-141 end to end on the GPU: the whole text, and
+    out.png in the working directory."""
+    import re
+    import subprocess
+    _mesh_dir(scenes, str(tmp_path))
+    out = subprocess.run([RT_MAIN, "--width", "320", "--height", "200", "--lights", "3"], cwd=str(tmp_path),
+                         capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    want = (r"RAY TRACING by Romain Roy\n-------------------------\nStart time: \d+:\d+:\d+\n"
+            r"Rendering image\.\.\. 0 %\rRendering image\.\.\. 100 %\r\nImage successfully saved!\n"
+            r"Finish time: \d+:\d+:\d+\nCompute time: 0:0:\d+\n"
+            r"Compute time \(ms\): [0-9.]+ \(320 x 200, 3 light samples, 1 GPU\(s\)\)\n$")
+    assert re.match(want, out.stdout.decode()), out.stdout
+    assert (tmp_path / "out.png").read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/meshs/bunny.off"), reason="reference tree not present")
+def test_mesh_files_hold_what_parse_reads_from_the_reference(host, scenes):
+    """ray-tracing_amd/data/*.mesh are the vertices and indices that parse() (meshs.h:60-125)
+    returns for the reference's own OFF files (bit for bit)."""
+    for name in ("bunny", "dino", "buddha"):
+        rc, v, f = host.parse_off("/root/reference/meshs/%s.off" % name)
+        assert rc == 0
+        v0, f0 = scenes.load_mesh(name)
+        assert np.array_equal(v.view(np.uint32), v0.view(np.uint32)) and np.array_equal(f, f0)
