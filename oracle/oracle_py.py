@@ -15,6 +15,8 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 capi = importlib.import_module("ray-tracing_amd.capi")
 
+ORC_FLAG_WAVE_SUM = 0x10000  # oracle-only bit of Params.flags (rtx_oracle.h)
+
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libref.so")
 

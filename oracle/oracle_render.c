@@ -288,6 +288,10 @@ static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pi
     v3 col = {0.f, 0.f, 0.f};
     v3 pos = hit.pos;
     float nl = (float)p->n_lights;
+    /* ORC_FLAG_WAVE_SUM: 64 partial sums, sample k to sum k % 64, combined pairwise at the end */
+    const int wave_sum = (p->flags & ORC_FLAG_WAVE_SUM) != 0;
+    v3 part[64];
+    if (wave_sum) memset(part, 0, sizeof(part));
     for (uint32_t k = 0; k < p->n_lights; k++) {
         float xy[2];
         orc_light_sample(p->seed, pixel, leaf_id, depth * p->n_lights + k, xy);
@@ -301,9 +305,20 @@ static int trace_leaf(const rtx_scene_desc *sc, const rtx_params *p, uint32_t pi
         if (occ < 0 || out_of_scene(sh.pos)) {
             v3 inv = v3_scale(d, -1.f);
             v3 c = shade(hit.nrm, inv, sd, lc, mat);
-            col = v3_add(col, v3_scale(v3_div(c, nl), 20.f));
+            if (wave_sum)
+                part[k & 63u] = v3_add(part[k & 63u], v3_scale(v3_div(c, nl), 20.f));
+            else
+                col = v3_add(col, v3_scale(v3_div(c, nl), 20.f));
             st->shaded_samples++;
         }
+    }
+    if (wave_sum) {
+        for (uint32_t off = 32; off >= 1; off >>= 1) {
+            v3 next[64];
+            for (uint32_t l = 0; l < 64; l++) next[l] = v3_add(part[l], part[l ^ off]);
+            memcpy(part, next, sizeof(part));
+        }
+        col = part[0];
     }
     v3 ret = col;
     if (depth < p->max_depth) {

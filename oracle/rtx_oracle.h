@@ -77,6 +77,13 @@ typedef struct orc_stats {
     uint64_t bounce_prim_tests;  /* primitive tests done for them */
 } orc_stats;
 
+/* Oracle-only bit of rtx_params::flags.  The reference adds the light samples of a hit one
+ * after the other (raytracing.h:36-50); a GPU wave adds sample k to the running sum of lane
+ * k % 64 and combines the 64 sums pairwise at the end (lane l with lane l ^ 32, ^ 16, ... ^ 1).
+ * With this bit the oracle adds in that order, so that a comparison with the GPU's colours
+ * (unsorted samples, IEEE build of the BSDF) is free of the order of summation. */
+#define ORC_FLAG_WAVE_SUM 0x10000u
+
 /* rgb: rtx_part_rows * width * 3 bytes (may be NULL).  hits: up to hit_cap
  * records in (pixel, ordinal) order (may be NULL); *n_hits gets the number
  * found.  fcolor: optional float RGB before clamp_color, same shape as rgb.

@@ -236,6 +236,43 @@ def test_sorted_sampling_flag(op, capi, built, cfg, w, h, nl):
     assert st_s.lit_samples == st_c.shaded_samples
 
 
+@pytest.mark.parametrize("cfg,depth,light_z,acne,nl,bounces,w,h", [
+    ("multi", 10, 420.0, 0.01, 150, 3, 200, 120),      # light inside the meshes, three mirror bounces
+    ("default", 8, 150.0, -0.01, 300, 2, 256, 256),    # negative offset: contributions of both signs
+    ("buddha", 10, 800.0, 0.01, 500, 0, 240, 200),
+    ("spheres", 10, 800.0, 0.01, 40, 4, 200, 200),
+    ("dino_spheres", 10, 30.0, 0.5, 17, 0, 200, 120),  # few-samples kernel
+])
+def test_colours_equal_the_oracles_in_the_same_order_of_summation(op, capi, scenes, rtx, cfg, depth, light_z,
+                                                                  acne, nl, bounces, w, h):
+    """What is left between a record's colour on the GPU and on the CPU once both add the
+    light samples in the same order (the oracle's ORC_FLAG_WAVE_SUM; the GPU with unsorted
+    samples and the IEEE build of the BSDF): the last bits of expf.  The wider bounds of the
+    other tests are the order of the sum (a channel that is the small remainder of cancelling
+    contributions carries the rounding of the large ones), not a different result."""
+    c = dict(scenes.CONFIGS[cfg])
+    c["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
+    b = op.OracleBuilder(depth)
+    d = scenes.assemble(b, c)
+    sc = rtx.Scene(d)
+    p = capi.default_params(w, h, nl, 21)
+    p.acne, p.max_depth = acne, bounces
+    p.flags = capi.RTX_FLAG_NO_SORT | capi.RTX_FLAG_IEEE_SHADE
+    rgb_g, hits_g = sc.render_hits(p)
+    q = capi.default_params(w, h, nl, 21)
+    q.acne, q.max_depth = acne, bounces
+    q.flags = op.ORC_FLAG_WAVE_SUM
+    rgb_c, _, hits_c, _ = op.render(d, q)
+    assert len(hits_c) > 1000
+    for k in ("pixel", "ordinal", "leaf", "prim"):
+        assert np.array_equal(hits_g[k], hits_c[k]), k
+    rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
+    err = np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-6 * rec_max + 1e-6)
+    assert err.max() < 2e-5, err.max()
+    assert float((rgb_g == rgb_c).mean()) > 0.9999
+    sc.close()
+
+
 def test_edge_shapes(op, capi, built):
     """Tiny and ragged frames, zero samples, a frame that misses everything."""
     _, d, sc = built("default")
