@@ -35,7 +35,7 @@ class FrameGather:
     """Gathers the equally padded tiles of all ranks to rank 0 and scatters their rows
     into one frame tensor there.  Buffers and the row index are allocated once; the
     scatter is a single index_copy_ (the padding rows of the tiles go to a spare row
-    behind the frame)."""
+    behind the frame).  With one rank the tile IS the frame: nothing to gather or move."""
 
     def __init__(self, torch, dist, height, width, stripe_rows, world, rank, device):
         self.torch, self.dist = torch, dist
@@ -56,11 +56,12 @@ class FrameGather:
             if world > 1:
                 self._stack = torch.zeros((world, self.pad_rows, width, 3), dtype=torch.uint8, device=device)
                 self.bufs = [self._stack[k] for k in range(world)]
+            else:
+                self.tile = self.frame
 
     def run(self):
         """Call on every rank after its tile has been rendered into self.tile."""
         if self.world == 1:
-            self._store.index_copy_(0, self.index, self.tile)
             return self.frame
         self.dist.gather(self.tile, self.bufs if self.rank == 0 else None, dst=0)
         if self.rank != 0:

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh.
+
+    python tools/hbm_traffic.py gpurun_out/round profiles/hbm_traffic.json
+
+Per workload: the last dispatch of the shading kernel in pmc_fetch_<w>.txt and
+pmc_write_<w>.txt (summaries by tools/pmc_summary.py; counters in KB)."""
+import json
+import re
+import sys
+
+
+def last_shade(path, counter):
+    val = None
+    for line in open(path):
+        if "shade_kernel" in line or "shade_few_kernel" in line:
+            m = re.search(counter + r"=([0-9.e+]+)", line)
+            if m:
+                val = float(m.group(1))
+    return val
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = {"note": "HBM bytes per launch of the shading kernel = (FETCH_SIZE + WRITE_SIZE) * 1024, raw rocprofv3 "
+                   "counters from separate --pmc runs (profiles/r2_pmc_hbm_<workload>.txt).  On gfx950 FETCH_SIZE "
+                   "reports half the bytes of wide coalesced streaming reads; this kernel reads through scalar "
+                   "loads and dword scratch reloads (uncalibrated widths), so the true figure lies between "
+                   "shade_kernel[w] and shade_kernel_upper[w] = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+           "shade_kernel": {}, "shade_kernel_upper": {}, "fetch_kb": {}, "write_kb": {}}
+    for w in ("buddha", "bunny", "dino_spheres", "multi", "default"):
+        try:
+            f = last_shade("%s/pmc_fetch_%s.txt" % (src, w), "FETCH_SIZE")
+            wr = last_shade("%s/pmc_write_%s.txt" % (src, w), "WRITE_SIZE")
+        except OSError:
+            continue
+        if f is None or wr is None:
+            continue
+        out["fetch_kb"][w], out["write_kb"][w] = f, wr
+        out["shade_kernel"][w] = int((f + wr) * 1024)
+        out["shade_kernel_upper"][w] = int((2 * f + wr) * 1024)
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out["shade_kernel"]))
+
+
+main()
