@@ -6,9 +6,12 @@
 A step is one frame of the workload: the image rows are dealt to the N ranks in stripes
 (one process per GPU, scene replicated), every rank renders its stripes through the C
 ABI (rtx_render_device) into device memory, and the stripes are gathered to rank 0 over
-RCCL.  The scene is uploaded once before the timed region.  --inflight frames (default 1)
-are in flight at a time per GPU; every timed frame is complete, gathered and assembled
-before the clock stops.  Rank 0 prints one JSON line:
+RCCL.  The scene is uploaded once before the timed region.  --inflight frames are in flight
+at a time per GPU (default: 1 on one GPU, so that the per-kernel times of the roofline
+block are those of a kernel that has the GPU to itself; 2 on several GPUs, where a rank's
+share of the frame is small and the gather and the kernels' last waves overlap with the next
+frame's kernels on separate HIP streams); every timed frame is complete, gathered and
+assembled before the clock stops.  Rank 0 prints one JSON line:
 
   value     Mrays/s = (primary rays + shadow rays) of the whole frame / frame time, both
             ray counts as counted by the renderer (pixels; hit records x light samples)
@@ -148,8 +151,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="buddha", choices=sorted(WORKLOADS))
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="frames in flight per GPU (own scene replica, stream and output tile each); with 2 "
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight per GPU; 0 (default) = 1 on one GPU, 2 on several (own scene replica, stream and output tile each); with 2 "
                          "the kernels of consecutive frames overlap: more frames per second, but a kernel's "
                          "HIP-event duration then includes the time it shares the GPU, so the roofline "
                          "figures are only meaningful with 1")
@@ -207,7 +210,7 @@ def main():
     # in frame order, so all ranks issue their collectives in the same order.  With more than
     # one slot a frame's low-occupancy phases (the trace kernel's heaviest tiles, the last
     # records of the shading kernel, the gather) overlap with the next frame's kernels.
-    n_slots = max(1, args.inflight)
+    n_slots = args.inflight if args.inflight > 0 else (1 if world == 1 else 2)
     replicas = [rtx.Scene(desc, local_rank) for _ in range(n_slots)]
     # (one slot: everything on the current stream, which also orders tile reuse)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [torch.cuda.current_stream()]
@@ -329,6 +332,9 @@ def main():
                 "frac_unfused": achieved / PEAK_FP32_UNFUSED_TFLOPS,
                 "traffic": traffic,
                 "launch_ms": shade_avg_ms,
+                "launch_ms_note": ("kernel alone on the GPU" if n_slots == 1 else
+                                   "%d frames in flight: the kernel shares the GPU with the other frame's kernels, "
+                                   "its duration (and frac) is not that of the kernel alone" % n_slots),
                 "executed_flop_per_launch": flop_run,
                 "flop_per_unit": {"prim_test": FLOP_PER_PRIM_TEST, "shadow_ray": FLOP_PER_SHADOW_RAY,
                                   "shaded_sample": FLOP_PER_SHADED_SAMPLE},

@@ -590,8 +590,9 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (hipError_t e = grow(&s->d_first, &s->pix_cap, npix); e != hipSuccess)
             return fail(RTX_ERR_NOMEM, std::string("pixel buffer: ") + hipGetErrorString(e));
         if (s->rec_cap == 0) {
-            // a first guess; a frame with more hits grows the buffers and is rendered again
-            rs = ensure_records(s, std::max<uint64_t>(npix / 2, 1u << 16));
+            // A first guess (96 bytes per record: 50 MB at 3840 x 2160); a frame with more hits
+            // grows the buffers to what it needs and is rendered again.
+            rs = ensure_records(s, std::max<uint64_t>(npix / 16, 1u << 16));
             if (rs != RTX_OK) return rs;
         }
         if (queued)
