@@ -273,6 +273,33 @@ def test_colours_equal_the_oracles_in_the_same_order_of_summation(op, capi, scen
     sc.close()
 
 
+@pytest.mark.parametrize("nl", [4, 200])
+def test_nested_fold_on_the_gpu(op, capi, rtx, nl):
+    """raytracing.h:85-93: every nesting level folds its own colours, and "replace if greater
+    in all three channels" is only a partial order, so that is not one running fold over all
+    leaves.  The hand-built scene whose two folds differ (see test_oracle_frames.py), through
+    merge_kernel: the frame must be the oracle's, and must differ from the flat fold where
+    the oracle's does."""
+    from handmade import nested_fold_scene
+    d, _keep = nested_fold_scene(capi)
+    sc = rtx.Scene(d)
+    p = capi.default_params(256, 256, nl, 1)
+    rgb_g, hits_g = sc.render_hits(p)
+    rgb_c, fcol, hits_c, _ = op.render(d, p)
+    check_hits(hits_g, hits_c)
+    assert np.abs(rgb_g.astype(np.int32) - rgb_c.astype(np.int32)).max() <= 1
+    # the flat fold of the GPU's own record colours, per pixel
+    flat = np.zeros((256 * 256, 3), np.float32)
+    for h in hits_g:                      # (pixel, ordinal) order
+        if (flat[h["pixel"]] < h["color"]).all():
+            flat[h["pixel"]] = h["color"]
+    flat_rgb = np.clip(flat, 0, 255).astype(np.uint8).reshape(256, 256, 3)
+    differs = (np.abs(flat_rgb.astype(np.int32) - rgb_c.astype(np.int32)).max(axis=2) > 1)
+    assert differs.sum() > 200            # the scene separates the two folds ...
+    assert (np.abs(rgb_g.astype(np.int32) - flat_rgb.astype(np.int32)).max(axis=2)[differs] > 1).all()  # ... and so does the GPU
+    sc.close()
+
+
 def test_edge_shapes(op, capi, built):
     """Tiny and ragged frames, zero samples, a frame that misses everything."""
     _, d, sc = built("default")

@@ -90,34 +90,8 @@ def test_nested_fold_is_not_a_flat_fold(op, capi):
     spheres behind one another in three leaf boxes, two of them inside an inner box:
     the result must be the per-level fold, which here differs from folding all leaves
     into one running colour."""
-    import ctypes as C
-    # build the description by hand: top-level [leaf A, inner [leaf B, leaf C]]
-    mats = (capi.Material * 3)()
-    for k, dif in enumerate([(0.20, 0.20, 0.20), (0.02, 0.60, 0.60), (0.25, 0.25, 0.25)]):
-        mats[k].ior, mats[k].roughness = 1.1, 0.9
-        mats[k].specular[:] = (0.0, 0.0, 0.0)
-        mats[k].diffuse[:] = dif
-    prims = (capi.Prim * 3)()
-    for k, z in enumerate([700.0, 500.0, 300.0]):
-        prims[k].type = capi.RTX_PRIM_SPHERE
-        prims[k].g[0:4] = (500.0, 500.0, z, 60.0)
-        prims[k].material, prims[k].id = k, k
-    nodes = (capi.Node * 4)()
-    big_lb, big_rt = (0.0, 0.0, 0.0), (1000.0, 1000.0, 1000.0)
-    for n in nodes:
-        n.lb[:], n.rt[:] = big_lb, big_rt
-    nodes[0].skip, nodes[0].leaf = 1, 0
-    nodes[1].skip, nodes[1].leaf = 4, capi.RTX_NONE
-    nodes[2].skip, nodes[2].leaf = 3, 1
-    nodes[3].skip, nodes[3].leaf = 4, 2
-    leaves = (capi.Leaf * 3)()
-    for k in range(3):
-        leaves[k].first, leaves[k].count = k, 1
-    d = capi.SceneDesc()
-    d.n_nodes, d.n_leaves, d.n_prims, d.n_materials = 4, 3, 3, 3
-    d.nodes, d.leaves, d.prims, d.materials = nodes, leaves, prims, mats
-    d.light.position[:] = (250.0, 250.0, 800.0)
-    d.light.color[:] = (255.0, 255.0, 255.0)
+    from handmade import nested_fold_scene
+    d, _keep = nested_fold_scene(capi)
     p = capi.default_params(64, 64, 4, 1)
     rgb, fcol, hits, _ = op.render(d, p)
     centre = hits[hits["pixel"] == 32 * 64 + 32]
