@@ -537,9 +537,20 @@ static TilePlan plan_tiles(const rtx_scene *s, const rtx_params *p, uint32_t row
     // Tiles through queues when the boxes leave a good part of the frame empty: only the
     // tile parts that can hit something are traced, each by the next free wave.  Where
     // nearly every tile has work the fixed assignment is cheaper.
-    t.queued = TRACE_QUEUE && tile_rects(s, p, &t.rects) < TRACE_QUEUE_MAX_COVER;
-    // lanes per primary ray: with queues the extra waves walk only the listed tiles
-    t.slices = (t.queued && s->trace_slices == 2) ? TRACE_SLICES_QUEUED : s->trace_slices;
+    const double cover = tile_rects(s, p, &t.rects);
+    t.queued = TRACE_QUEUE && cover < TRACE_QUEUE_MAX_COVER;
+    // Lanes per primary ray.  With queues the extra waves walk only the listed tiles.  In a
+    // scene with large leaves two lanes share a ray; when the listed tile parts (8 x 4 pixels
+    // each, estimated from the rectangles' area) are fewer than three quarters of the resident
+    // waves - a small frame, or one GPU's share of a split frame - the kernel lasts as long as
+    // its heaviest parts, and four lanes per ray halve those (measured on buddha, bunny and
+    // the multi-mesh scene at 1, 1/2, 1/4 and 1/8 of their frames).
+    t.slices = s->trace_slices;
+    if (t.queued && s->trace_slices == 2) {
+        const double listed = cover * (double)rows * p->width / 32.0;
+        const double resident = (double)s->n_cu * TRACE_QUEUE_BLOCKS_PER_CU * (TRACE_BLOCK / 64);
+        t.slices = (listed < 0.75 * resident) ? 4u : TRACE_SLICES_QUEUED;
+    }
     t.tile_h = 16 / t.slices;
     t.tiles = ((p->width + 15) / 16) * ((rows + t.tile_h - 1) / t.tile_h);
     t.tile_seg = 4 * ((t.tiles + TILE_QUEUES - 1) / TILE_QUEUES);
