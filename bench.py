@@ -281,11 +281,14 @@ def main():
     # the call), outside the timed region; never `value`
     host_ms = None
     if args.host_steps > 0:
+        host_frame = rtx.HostFrame(rtx.part_rows(p), w)     # page-locked output buffer
+        replicas[0].render_into(p, host_frame)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.host_steps):
-            replicas[0].render(p)
+            replicas[0].render_into(p, host_frame)
         host_ms = (time.perf_counter() - t0) / args.host_steps * 1e3
+        host_frame.close()
         if world > 1:
             hm = torch.tensor([host_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(hm, op=dist.ReduceOp.MAX)

@@ -45,6 +45,8 @@ def lib():
         L.rtx_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p,
                                         C.POINTER(Stats)]
         L.rtx_render_device_static.argtypes = L.rtx_render_device.argtypes
+        L.rtx_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        L.rtx_host_free.argtypes = [C.c_void_p]
         L.rtx_render_hits.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_uint64,
                                       C.POINTER(C.c_uint64), C.c_void_p]
         _lib = L
@@ -67,6 +69,23 @@ def selftest(device=0):
     return dict(rcp_checked=int(out[0]), rcp_mismatches=int(out[1]), chain_checked=int(out[2]),
                 chain_mismatches=int(out[3]), chain_declined=int(out[4]), div_checked=int(out[5]),
                 div_mismatches=int(out[6]))
+
+
+class HostFrame:
+    """Page-locked host memory for a frame (rtx_host_alloc), viewed as a numpy array."""
+
+    def __init__(self, rows, width):
+        self._p = C.c_void_p()
+        self.nbytes = rows * width * 3
+        _check(lib().rtx_host_alloc(self.nbytes, C.byref(self._p)))
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, np.uint8, self.nbytes).reshape(rows, width, 3)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().rtx_host_free(self._p)
+            self._p = C.c_void_p()
 
 
 class Scene:
@@ -96,6 +115,12 @@ class Scene:
             p.flags |= capi.RTX_FLAG_TIMING
         _check(lib().rtx_render(self._h, C.byref(p), rgb.ctypes.data, C.byref(st)))
         return rgb, st
+
+    def render_into(self, p, frame):
+        """rtx_render into a HostFrame (page-locked: the read-back runs at the link's rate)."""
+        st = Stats()
+        _check(lib().rtx_render(self._h, C.byref(p), frame.array.ctypes.data, C.byref(st)))
+        return st
 
     def render_device(self, p, d_rgb, stream=0, stats=True):
         """Render into device memory at address d_rgb on HIP stream `stream`."""

@@ -459,6 +459,19 @@ def test_large_coordinates(op, capi, scenes, rtx, position, taille, light_z):
     sc.close()
 
 
+def test_page_locked_output(capi, rtx, built):
+    """rtx_render into memory from rtx_host_alloc gives the bytes it gives into ordinary memory."""
+    _, d, sc = built("bunny")
+    p = capi.default_params(640, 360, 20, 3)
+    p.stripe_rows, p.n_parts, p.part = 8, 3, 2
+    rgb, _ = sc.render(p)
+    frame = rtx.HostFrame(rtx.part_rows(p), p.width)
+    frame.array[:] = 7
+    st = sc.render_into(p, frame)
+    assert st.hits > 1000 and np.array_equal(frame.array, rgb)
+    frame.close()
+
+
 def test_record_buffer_growth(op, capi, rtx, scenes):
     """A first frame with far more hits than the initial record buffer holds."""
     b = op.OracleBuilder(10)
