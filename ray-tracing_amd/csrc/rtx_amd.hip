@@ -623,7 +623,10 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
     const uint32_t trace_blocks = (uint32_t)s->n_cu * TRACE_BLOCKS_PER_CU;
-    const uint32_t shade_blocks = (uint32_t)s->n_cu * (p->max_depth ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD);
+    const uint32_t shade_waves = p->max_depth ? SHADE_WAVES_PER_SIMD_BOUNCE
+                                 : fr.sort_samples ? SHADE_WAVES_PER_SIMD_SORT
+                                                   : SHADE_WAVES_PER_SIMD;
+    const uint32_t shade_blocks = (uint32_t)s->n_cu * shade_waves;
     const uint32_t merge_blocks = (uint32_t)((npix + MERGE_BLOCK - 1) / MERGE_BLOCK);
 
     uint64_t n_hits = 0;
@@ -660,9 +663,9 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             shade_few_kernel<G, false><<<few_blocks, SHADE_BLOCK, 0, st>>>(                                \
                 fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr);                    \
     } while (0)
-#define LAUNCH_SHADE(B, I)                                                                                   \
-    shade_kernel<B, I><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, wb.recs,          \
-                                                             wb.rec_cap, wb.colors, wb.ctr)
+#define LAUNCH_SHADE(B, I, W)                                                                                \
+    shade_kernel<B, I, W><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, wb.recs,       \
+                                                                wb.rec_cap, wb.colors, wb.ctr)
         const uint32_t nlg = p->n_lights;
         const bool ieee = (p->flags & RTX_FLAG_IEEE_SHADE) != 0;
         const bool few = p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
@@ -677,12 +680,15 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             else if (nlg <= 8) LAUNCH_FEW(8);
             else if (nlg <= 16) LAUNCH_FEW(16);
             else LAUNCH_FEW(32);
+        } else if (p->max_depth == 0 && fr.sort_samples) {
+            if (ieee) LAUNCH_SHADE(false, true, SHADE_WAVES_PER_SIMD_SORT);
+            else LAUNCH_SHADE(false, false, SHADE_WAVES_PER_SIMD_SORT);
         } else if (p->max_depth == 0) {
-            if (ieee) LAUNCH_SHADE(false, true);
-            else LAUNCH_SHADE(false, false);
+            if (ieee) LAUNCH_SHADE(false, true, SHADE_WAVES_PER_SIMD);
+            else LAUNCH_SHADE(false, false, SHADE_WAVES_PER_SIMD);
         } else {
-            if (ieee) LAUNCH_SHADE(true, true);
-            else LAUNCH_SHADE(true, false);
+            if (ieee) LAUNCH_SHADE(true, true, SHADE_WAVES_PER_SIMD_BOUNCE);
+            else LAUNCH_SHADE(true, false, SHADE_WAVES_PER_SIMD_BOUNCE);
         }
         if (timing) HIP_TRY(hipEventRecord(s->ev[2], st));
         merge_kernel<<<merge_blocks, MERGE_BLOCK, (size_t)s->nest_levels * 3 * MERGE_BLOCK * sizeof(float), st>>>(fr, s->d_nodes, s->d_up, wb.recs,

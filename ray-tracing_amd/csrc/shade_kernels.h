@@ -121,9 +121,10 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
     }
 }
 
-template <bool BOUNCE, bool IEEE>
-__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(BOUNCE ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD,
-                                                   BOUNCE ? SHADE_WAVES_PER_SIMD_BOUNCE : SHADE_WAVES_PER_SIMD)))
+// WAVES: waves per SIMD the kernel is compiled for (its register budget); the host launches
+// exactly that many per SIMD.
+template <bool BOUNCE, bool IEEE, int WAVES>
+__global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void shade_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
     const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
