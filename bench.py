@@ -185,6 +185,8 @@ def main():
     backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
     if os.environ.get("RTX_BENCH_SHARE_GPU") == "1":
         local_rank %= torch.cuda.device_count()
+    elif world > 1 and torch.cuda.device_count() == 1:
+        local_rank = 0   # the launcher shows every rank its own GPU only
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
