@@ -438,6 +438,21 @@ __device__ __forceinline__ bool acne_chain_delta(float p0, float c, uint32_t n, 
     return (__float_as_uint(pend) >> 23) == (bits >> 23);
 }
 
+// acne_chain_delta for the three components of a wave-uniform hit position and step: lanes
+// 0, 1 and 2 take one component each (the same arithmetic; done component after component in
+// every lane it costs three times the instructions).  All lanes of the wave must be active.
+__device__ __forceinline__ bool acne_chain_delta3(uint32_t lane, f3 p0, f3 step, uint32_t n, f3 &dlt) {
+    const float pc = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
+    const float sc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
+    float dc = 0.f;
+    const bool ok = acne_chain_delta(pc, sc, n, dc);
+    const int bits = __float_as_int(dc);
+    dlt.x = __int_as_float(__builtin_amdgcn_readlane(bits, 0));
+    dlt.y = __int_as_float(__builtin_amdgcn_readlane(bits, 1));
+    dlt.z = __int_as_float(__builtin_amdgcn_readlane(bits, 2));
+    return (__ballot(ok) & 7ull) == 7ull;
+}
+
 // ---- light sampler -------------------------------------------------------------
 // Philox-2x32-10, key = seed, counter = (pixel, leaf << 16 | sample); each
 // output word is mapped to 0..500 by a 32x32 -> high-32 multiply with 501.
@@ -471,6 +486,20 @@ __device__ __forceinline__ void light_sample(uint32_t seed, uint32_t pixel, uint
 __device__ __forceinline__ void primary_ray(const DFrame &fr, uint32_t i, uint32_t j, f3 &o, f3 &d) {
     o = f3_make(500.f + ((float)i - fr.half_width) * fr.scale, (float)j * fr.scale, 1000.f);
     d = f3_normalize(f3_sub(o, fr.camera));
+}
+
+// primary_ray for a wave-uniform pixel: the three divisions of normalize (vec3.h:28-31) in
+// lanes 0, 1 and 2 at once.  All lanes of the wave must be active.
+__device__ __forceinline__ void primary_ray_uniform(const DFrame &fr, uint32_t i, uint32_t j, uint32_t lane, f3 &o,
+                                                    f3 &d) {
+    o = f3_make(500.f + ((float)i - fr.half_width) * fr.scale, (float)j * fr.scale, 1000.f);
+    const f3 v = f3_sub(o, fr.camera);
+    const float len = __builtin_sqrtf(f3_dot(v, v));
+    const float q = (lane == 0 ? v.x : lane == 1 ? v.y : v.z) / len;
+    const int bits = __float_as_int(q);
+    d.x = __int_as_float(__builtin_amdgcn_readlane(bits, 0));
+    d.y = __int_as_float(__builtin_amdgcn_readlane(bits, 1));
+    d.z = __int_as_float(__builtin_amdgcn_readlane(bits, 2));
 }
 
 // Global row of local row r of this part (rows are dealt to parts in stripes).

@@ -293,7 +293,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
         f3 p0 = f3_make(rc.px, rc.py, rc.pz);
         f3 o, d;
-        primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
         uint32_t depth = 0;
         for (;;) {
         const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
@@ -302,10 +302,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         // shadow-ray origins: closed form where provably exact, else the serial chain run
         // by lanes 0..2 (running origin component and its increment)
         f3 dlt = f3_make(0.f, 0.f, 0.f);
-        const bool cx = acne_chain_delta(p0.x, step.x, fr.n_lights, dlt.x);
-        const bool cy = acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
-        const bool cz = acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
-        const bool closed = cx && cy && cz;
+        const bool closed = acne_chain_delta3(lane, p0, step, fr.n_lights, dlt);
 #ifdef STEP_STATS
         tot.st[9] += !closed;
 #endif

@@ -291,13 +291,11 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
         const f3 p0 = f3_make(rc.px, rc.py, rc.pz);
         f3 o, d;
-        primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
         const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
         const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
         f3 dlt = f3_make(0.f, 0.f, 0.f);        // origin of sample k = p0 + (k + 1) * dlt
-        acne_chain_delta(p0.x, step.x, fr.n_lights, dlt.x);
-        acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
-        acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
+        acne_chain_delta3(lane, p0, step, fr.n_lights, dlt);
 
         uint32_t n_cand;
         bool use_sort;
