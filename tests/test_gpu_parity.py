@@ -691,3 +691,39 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
     assert "verify slot 0: assembled frame equals" in out.stderr
+
+
+@pytest.mark.gpu
+def test_collectives_of_the_bench_run_over_rccl():
+    """The calls bench.py and FrameGather make on several GPUs, over RCCL itself (one rank:
+    all a one-GPU box can hold): init with a device id, a gather of uint8 stripe views into
+    slices of one stacked tensor, float64 MAX / SUM all-reduces, barrier, destroy."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = r"""
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+tile = torch.randint(0, 256, (136, 3840, 3), dtype=torch.uint8, device=dev)
+stack = torch.zeros((1, 136, 3840, 3), dtype=torch.uint8, device=dev)
+dist.gather(tile, [stack[0]], dst=0)
+c = torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev)
+m = c.clone()
+dist.all_reduce(m, op=dist.ReduceOp.MAX)
+dist.all_reduce(c, op=dist.ReduceOp.SUM)
+dist.barrier()
+torch.cuda.synchronize()
+assert bool((stack[0] == tile).all()) and m.tolist() == [1.5, 2.0] and c.tolist() == [1.5, 2.0]
+dist.destroy_process_group()
+print("rccl ok")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
