@@ -201,9 +201,11 @@ const char *rtx_last_error(void);
  *   out[2], out[3]  cases checked / mismatching cases of the closed form of the acne
  *                   offset chain against the step-by-step float additions
  *                   (raytracing.h:40); out[4] = cases the closed form declined
- *   out[5], out[6]  values checked / mismatches of the packed division by a shared
- *                   denominator and of the two-vector normalisation built on it against
- *                   `v / sqrt(dot(v, v))` (vec3.h:28-31)
+ *   out[5], out[6]  values checked / mismatches of the parts of the two-vector normalisation
+ *                   against `v / sqrt(dot(v, v))` (vec3.h:28-31): the packed square root
+ *                   against sqrtf (every binary32 value of its working range), the packed
+ *                   division by a shared denominator and the normalisation as a whole
+ *                   (pseudo-random operands)
  * Mismatches must be 0. */
 rtx_status rtx_selftest(int device, uint64_t out[7]);
 

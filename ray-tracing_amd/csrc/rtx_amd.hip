@@ -142,7 +142,7 @@ extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) {
     HIP_TRY(hipMalloc((void **)&d, 56));
     hipError_t e = hipMemset(d, 0, 56);
     if (e == hipSuccess) {
-        selftest_rcp_kernel<<<4096, 256>>>(d + 1, d);
+        selftest_rcp_kernel<<<4096, 256>>>(d + 1, d, d + 6, d + 5);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) {

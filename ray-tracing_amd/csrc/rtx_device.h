@@ -267,22 +267,40 @@ __device__ __forceinline__ v2f div2_exact(v2f n, const recip2 &R) {
     return __builtin_elementwise_fma(e2, R.r, q1);
 }
 
+// sqrtf of two values at once, bit-identical to the correctly rounded square root for
+// SQRT2_MIN <= x <= SQRT2_MAX: g = x * rsq(x) (v_rsq_f32, 1 ulp) is within 2 ulp of the
+// root, the fused d = x - g * g is exact, and g + d * (rsq(x) / 2) then has a relative
+// error of about 2^-47 before its rounding; no square root of a binary32 value lies that
+// close to the midpoint of two neighbours.  rtx_selftest() compares with sqrtf for every
+// value of the range.  (The compiler's expansion: v_sqrt_f32, two trial residuals one ulp
+// below and above, range scaling and special cases, 16 instructions per value.)
+#define SQRT2_MIN 1.0e-30f
+#define SQRT2_MAX 1.0e30f
+__device__ __forceinline__ v2f sqrt2_exact(v2f x) {
+    const v2f y = (v2f){__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    const v2f g = x * y, h = 0.5f * y;
+    const v2f d = __builtin_elementwise_fma(-g, g, x);
+    return __builtin_elementwise_fma(d, h, g);
+}
+
 // f3_normalize of two vectors at once (x, y, z hold the pairs of components), bit for bit.
 __device__ __forceinline__ void normalize2(v2f &x, v2f &y, v2f &z) {
     const v2f dd = x * x + y * y + z * z;
-    const v2f len = (v2f){__builtin_sqrtf(dd.x), __builtin_sqrtf(dd.y)};
-    // smallest |component| of each vector (a NaN component makes the norm NaN, which fails
-    // the range test on the norm, so fminf dropping NaNs loses nothing)
+    // smallest |component| of each vector (a NaN component makes the squared norm NaN, which
+    // fails the range test on it, so fminf dropping NaNs loses nothing)
     const float lo1 = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x.x), __builtin_fabsf(y.x)), __builtin_fabsf(z.x));
     const float lo2 = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x.y), __builtin_fabsf(y.y)), __builtin_fabsf(z.y));
-    const bool plain = len.x >= DIV2_DEN_MIN && len.x <= DIV2_DEN_MAX && len.y >= DIV2_DEN_MIN &&
-                       len.y <= DIV2_DEN_MAX && lo1 >= DIV2_NUM_MIN && lo2 >= DIV2_NUM_MIN;
+    // squared norms whose root lies inside DIV2_DEN_MIN .. DIV2_DEN_MAX (and inside sqrt2_exact's range)
+    const float dd_min = DIV2_DEN_MIN * DIV2_DEN_MIN * 1.001f, dd_max = DIV2_DEN_MAX * DIV2_DEN_MAX * 0.999f;
+    const bool plain = dd.x >= dd_min && dd.x <= dd_max && dd.y >= dd_min && dd.y <= dd_max &&
+                       lo1 >= DIV2_NUM_MIN && lo2 >= DIV2_NUM_MIN;
     if (__builtin_expect(__all(plain), 1)) {
-        const recip2 R = recip2_make(len);
+        const recip2 R = recip2_make(sqrt2_exact(dd));
         x = div2_exact(x, R);
         y = div2_exact(y, R);
         z = div2_exact(z, R);
     } else { // a zero or extreme component somewhere in the wave
+        const v2f len = (v2f){__builtin_sqrtf(dd.x), __builtin_sqrtf(dd.y)};
         x = x / len;
         y = y / len;
         z = z / len;
@@ -301,21 +319,20 @@ struct ray2 {
 };
 
 // 1 / a for two values at once, bit-identical to the correctly rounded IEEE quotient
-// 1.f / a for RCP2_MIN <= |a| < RCP2_MAX: the same v_rcp_f32 seed and the same six
-// fused multiply-adds that the compiler's division expansion performs when no
-// operand scaling is needed, issued as packed v_pk_fma_f32.  Verified exhaustively
-// over that range by rtx_selftest().  Outside the range use the plain division.
+// 1.f / a for RCP2_MIN <= |a| < RCP2_MAX: the v_rcp_f32 seed (1 ulp) and one Newton step
+// with fused multiply-adds, issued as packed v_pk_fma_f32.  The step leaves a relative
+// error of about 2^-46 before its final rounding, and no reciprocal of a binary32 value
+// lies that close to the midpoint of two neighbours: rtx_selftest() compares the result
+// with 1.f / a for every value of the range (the compiler's expansion of the division
+// goes on with two more correction steps, which never change a bit here).  Outside the
+// range use the plain division.
 #define RCP2_MIN 5.0e-8f
 #define RCP2_MAX 1.0e18f
 __device__ __forceinline__ v2f rcp2_exact(v2f a) {
     const v2f one = (v2f){1.f, 1.f};
     const v2f r0 = (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
     const v2f e0 = __builtin_elementwise_fma(-a, r0, one);
-    const v2f r1 = __builtin_elementwise_fma(e0, r0, r0);
-    const v2f e1 = __builtin_elementwise_fma(-a, r1, one);
-    const v2f r2 = __builtin_elementwise_fma(e1, r1, r1);
-    const v2f e2 = __builtin_elementwise_fma(-a, r2, one);
-    return __builtin_elementwise_fma(e2, r1, r2);
+    return __builtin_elementwise_fma(e0, r0, r0);
 }
 
 // tri_hit on a pair of (ray, triangle) problems at once.  R is the type of the ray's

@@ -3,10 +3,12 @@
 #pragma once
 
 // ---- self test ------------------------------------------------------------------
-// rcp2_exact against the plain division for every binary32 value in its range.
-__global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long *checked) {
+// rcp2_exact against the plain division and sqrt2_exact against sqrtf, for every binary32
+// value in their ranges.
+__global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long *checked,
+                                    unsigned long long *bad_sqrt, unsigned long long *checked_sqrt) {
     const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t nb = 0, nc = 0;
+    uint32_t nb = 0, nc = 0, sb = 0, sc = 0;
     // 2^32 bit patterns, two per iteration
     for (unsigned long long i = (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 2; i < (1ull << 32);
          i += (unsigned long long)stride * 2) {
@@ -22,9 +24,20 @@ __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long 
             nc++;
             nb += __float_as_uint(r.y) != __float_as_uint(1.f / y);
         }
+        const v2f q = sqrt2_exact((v2f){x, y});
+        if (x >= SQRT2_MIN && x <= SQRT2_MAX) {
+            sc++;
+            sb += __float_as_uint(q.x) != __float_as_uint(__builtin_sqrtf(x));
+        }
+        if (y >= SQRT2_MIN && y <= SQRT2_MAX) {
+            sc++;
+            sb += __float_as_uint(q.y) != __float_as_uint(__builtin_sqrtf(y));
+        }
     }
     if (nb) atomicAdd(bad, (unsigned long long)nb);
     atomicAdd(checked, (unsigned long long)nc);
+    if (sb) atomicAdd(bad_sqrt, (unsigned long long)sb);
+    atomicAdd(checked_sqrt, (unsigned long long)sc);
 }
 
 // div2_exact / normalize2 against the plain quotient: pseudo-random denominators over
