@@ -341,28 +341,30 @@ __device__ __forceinline__ v2f rcp2_exact(v2f a) {
 // operation tri_hit performs, on both problems in one packed instruction.  EARLY_OUT =
 // false runs every problem to the end (straight-line code: worth it where the wave has
 // the SIMD to itself and the branches of the early exits cost more than the arithmetic).
-template <typename R, typename P, bool EARLY_OUT = true>
+// ok1 / ok2: whether the problem takes part.  on_hit(hit1, hit2, t) is called once all
+// tests are done, unless an early exit found that neither problem can hit: what the
+// caller does with a hit (keep the nearest) then sits behind the exits, in the part of
+// the code that few steps reach, and no distance has to exist on the other paths.
+template <typename R, typename P, bool EARLY_OUT = true, typename F>
 __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P v0x, P v0y, P v0z, P e1x, P e1y,
-                                           P e1z, P e2x, P e2y, P e2z, bool check_wide, bool &ok1, bool &ok2,
-                                           v2f &t) {
+                                           P e1z, P e2x, P e2y, P e2z, bool check_wide, bool ok1, bool ok2,
+                                           F &&on_hit) {
     const float eps = 0.0000001f;
     const v2f hx = dy * e2z - dz * e2y;
     const v2f hy = dz * e2x - dx * e2z;
     const v2f hz = dx * e2y - dy * e2x;
     const v2f a = e1x * hx + e1y * hy + e1z * hz;
+    // (no exit here: a determinant this small is rare, and a problem that fails goes on with
+    // values that are never used)
     ok1 = ok1 && !(a.x > -eps && a.x < eps);
     ok2 = ok2 && !(a.y > -eps && a.y < eps);
-    if (EARLY_OUT && !(ok1 || ok2)) return;
     // |a| >= 1e-7 for every problem still open; the upper end of rcp2_exact's range needs a
     // check only in a scene with triangle edges so long that |a| <= |e1| |e2| could reach it
-    bool wide = false;
-    if (check_wide)
-        wide = __any((ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX)));
-    v2f f;
-    if (__builtin_expect(wide, 0))
-        f = 1.f / a;
-    else
-        f = rcp2_exact(a);
+    v2f f = rcp2_exact(a);
+    if (__builtin_expect(check_wide, 0)) {
+        if (__any((ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX))))
+            f = 1.f / a;
+    }
     const v2f sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
     const v2f u = f * (sx * hx + sy * hy + sz * hz);
     ok1 = ok1 && !(u.x < 0.f || u.x > 1.f);
@@ -376,16 +378,16 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
     ok1 = ok1 && !(v.x < 0.f || uv.x > 1.f);
     ok2 = ok2 && !(v.y < 0.f || uv.y > 1.f);
     if (EARLY_OUT && !(ok1 || ok2)) return;
-    t = f * (e2x * qx + e2y * qy + e2z * qz);
-    ok1 = ok1 && t.x > eps;
-    ok2 = ok2 && t.y > eps;
+    const v2f t = f * (e2x * qx + e2y * qy + e2z * qz);
+    on_hit(ok1 && t.x > eps, ok2 && t.y > eps, t);
 }
 
 // two rays, one triangle
-__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool check_wide, bool &ok1, bool &ok2,
-                                         v2f &t) {
+template <typename F>
+__device__ __forceinline__ void tri_hit2(const ray2 &r, f3 v0, f3 e1, f3 e2, bool check_wide, bool ok1, bool ok2,
+                                         F &&on_hit) {
     tri_hit_pk<v2f, float>(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z,
-                           check_wide, ok1, ok2, t);
+                           check_wide, ok1, ok2, on_hit);
 }
 
 // intersect.h:1-18 (distance only)

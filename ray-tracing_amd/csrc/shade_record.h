@@ -371,8 +371,9 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             normalize2(rr.dx, rr.dy, rr.dz);
             const f3 sd1 = f3_make(rr.dx.x, rr.dy.x, rr.dz.x), sd2 = f3_make(rr.dx.y, rr.dy.y, rr.dz.y);
             // nearest hit of each shadow ray inside the leaf (raytracing.h:45)
-            float tmin1 = 0.f, tmin2 = 0.f;
-            bool any1 = false, any2 = false;
+            // (no hit yet = +infinity: a hit at t = +inf, were there one, puts the point
+                // out of the scene, which lights the sample just as no hit does)
+                float tmin1 = __builtin_inff(), tmin2 = __builtin_inff();
             for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
@@ -389,34 +390,29 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                     const uint32_t cn = __builtin_amdgcn_readfirstlane(
                         (uint32_t)L.cand[(c + 1 < n_cand) ? c + 1 : c]);
                     const DPrim nxt = leaf_prims[seg + cn];
-                    bool ok1 = live1, ok2 = live2;
-                    v2f t = (v2f){0.f, 0.f};
+                    // the nearest hit so far (raytracing.h:45 takes the smallest distance)
+                    const auto nearest = [&](bool hit1, bool hit2, v2f t) {
+                        if (hit1 && t.x < tmin1) tmin1 = t.x;
+                        if (hit2 && t.y < tmin2) tmin2 = t.y;
+                    };
 #ifdef STEP_STATS
                     step_stats(tot, rr, cur, live1, live2);
 #endif
                     if ((cur.type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                        tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, ok1, ok2, t);
+                        tri_hit2(rr, cur.a, cur.b, cur.c, fr.wide_dets != 0, live1, live2, nearest);
                     } else {
                         float ta = 0.f, tb = 0.f;
-                        ok1 = ok1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
-                        ok2 = ok2 && sph_hit(p2, sd2, cur.a, cur.b.y, tb);
-                        t = (v2f){ta, tb};
-                    }
-                    if (ok1 && (!any1 || t.x < tmin1)) {
-                        tmin1 = t.x;
-                        any1 = true;
-                    }
-                    if (ok2 && (!any2 || t.y < tmin2)) {
-                        tmin2 = t.y;
-                        any2 = true;
+                        const bool hit1 = live1 && sph_hit(p1, sd1, cur.a, cur.b.y, ta);
+                        const bool hit2 = live2 && sph_hit(p2, sd2, cur.a, cur.b.y, tb);
+                        nearest(hit1, hit2, (v2f){ta, tb});
                     }
                     cur = nxt;
                 }
             }
             // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
             // samples of a lane are added in sample order
-            const bool lit1 = live1 && (!any1 || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
-            const bool lit2 = live2 && (!any2 || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
+            const bool lit1 = live1 && (!(tmin1 < __builtin_inff()) || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
+            const bool lit2 = live2 && (!(tmin2 < __builtin_inff()) || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
             if (lit1 || lit2) {
                 f3 c1, c2;
                 shade2<IEEE>(nrm, view, rr.dx, rr.dy, rr.dz, lit1, lit2, fr.light_color, mat, nl, c1, c2);

@@ -141,20 +141,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
                         if (hit && mine_pair) {
                             const uint32_t ka = base + 2 * pr;
                             if (type_a == RTX_PRIM_TRIANGLE && type_b == RTX_PRIM_TRIANGLE) {
-                                bool ok_a = true, ok_b = true;
-                                v2f t = (v2f){0.f, 0.f};
-                                tri_hit_pk<float, v2f, TRACE_EARLY_OUT>(o.x, o.y, o.z, d.x, d.y, d.z, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w},
-                                                       (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.x, q2.y},
-                                                       (v2f){q2.z, q2.w}, (v2f){q3.x, q3.y}, (v2f){q3.z, q3.w},
-                                                       (v2f){q4.x, q4.y}, fr.wide_dets != 0, ok_a, ok_b, t);
-                                if (ok_a && (best == RTXD_NONE || t.x < best_t)) {
-                                    best_t = t.x;
-                                    best = ka;
-                                }
-                                if (ok_b && (best == RTXD_NONE || t.y < best_t)) {
-                                    best_t = t.y;
-                                    best = ka + 1;
-                                }
+                                tri_hit_pk<float, v2f, TRACE_EARLY_OUT>(
+                                    o.x, o.y, o.z, d.x, d.y, d.z, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q1.x, q1.y},
+                                    (v2f){q1.z, q1.w}, (v2f){q2.x, q2.y}, (v2f){q2.z, q2.w}, (v2f){q3.x, q3.y},
+                                    (v2f){q3.z, q3.w}, (v2f){q4.x, q4.y}, fr.wide_dets != 0, true, true,
+                                    [&](bool hit_a, bool hit_b, v2f t) {
+                                        if (hit_a && (best == RTXD_NONE || t.x < best_t)) {
+                                            best_t = t.x;
+                                            best = ka;
+                                        }
+                                        if (hit_b && (best == RTXD_NONE || t.y < best_t)) {
+                                            best_t = t.y;
+                                            best = ka + 1;
+                                        }
+                                    });
                             } else { // a sphere, or the odd primitive at the end of the leaf
                                 float t;
                                 bool ok = false;
