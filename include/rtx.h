@@ -197,7 +197,9 @@ const char *rtx_last_error(void);
  * the kernels are compared with the plain IEEE evaluation they replace:
  *   out[0], out[1]  values checked / mismatches of the packed reciprocal against the
  *                   correctly rounded quotient 1.f / a (the reference's `f = 1.f / a`,
- *                   intersect.h:41), every binary32 value of its working range
+ *                   intersect.h:41), every binary32 value of its working range; and of
+ *                   `|f| > 1e7f` against `-eps < a < eps` (intersect.h:39), every
+ *                   binary32 value
  *   out[2], out[3]  cases checked / mismatching cases of the closed form of the acne
  *                   offset chain against the step-by-step float additions
  *                   (raytracing.h:40); out[4] = cases the closed form declined

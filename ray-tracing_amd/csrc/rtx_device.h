@@ -354,12 +354,13 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
     const v2f hy = dz * e2x - dx * e2z;
     const v2f hz = dx * e2y - dy * e2x;
     const v2f a = e1x * hx + e1y * hy + e1z * hz;
-    // (no exit here: a determinant this small is rare, and a problem that fails goes on with
-    // values that are never used)
-    ok1 = ok1 && !(a.x > -eps && a.x < eps);
-    ok2 = ok2 && !(a.y > -eps && a.y < eps);
-    // |a| >= 1e-7 for every problem still open; the upper end of rcp2_exact's range needs a
-    // check only in a scene with triangle edges so long that |a| <= |e1| |e2| could reach it
+    // intersect.h:39 gives up when -eps < a < eps.  That test is made on f = 1 / a, at the
+    // end: for the correctly rounded f, |a| < eps exactly when |f| > 1e7f (1 / eps rounds to
+    // 1e7f and the reciprocal of the float below eps to 10000001); a = 0 or a subnormal a
+    // make f infinite or NaN, and `|f| <= 1e7f` is false for these; a NaN or infinite a
+    // makes t NaN or zero in the reference, which fails `t > eps` there.  A problem that fails it goes on with values nobody uses.
+    // (The upper end of rcp2_exact's range needs a check only in a scene with triangle edges
+    // so long that |a| <= |e1| |e2| could reach it.)
     v2f f = rcp2_exact(a);
     if (__builtin_expect(check_wide, 0)) {
         if (__any((ok1 && !(__builtin_fabsf(a.x) < RCP2_MAX)) || (ok2 && !(__builtin_fabsf(a.y) < RCP2_MAX))))
@@ -379,7 +380,8 @@ __device__ __forceinline__ void tri_hit_pk(R ox, R oy, R oz, R dx, R dy, R dz, P
     ok2 = ok2 && !(v.y < 0.f || uv.y > 1.f);
     if (EARLY_OUT && !(ok1 || ok2)) return;
     const v2f t = f * (e2x * qx + e2y * qy + e2z * qz);
-    on_hit(ok1 && t.x > eps, ok2 && t.y > eps, t);
+    const float f_max = 10000000.f; // 1 / eps
+    on_hit(ok1 && __builtin_fabsf(f.x) <= f_max && t.x > eps, ok2 && __builtin_fabsf(f.y) <= f_max && t.y > eps, t);
 }
 
 // two rays, one triangle

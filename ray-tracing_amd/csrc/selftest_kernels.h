@@ -4,7 +4,8 @@
 
 // ---- self test ------------------------------------------------------------------
 // rcp2_exact against the plain division and sqrt2_exact against sqrtf, for every binary32
-// value in their ranges.
+// value in their ranges; the threshold on the reciprocal that stands for intersect.h:39's
+// test of the determinant, for every binary32 value.
 __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long *checked,
                                     unsigned long long *bad_sqrt, unsigned long long *checked_sqrt) {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -23,6 +24,17 @@ __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long 
         if (iny) {
             nc++;
             nb += __float_as_uint(r.y) != __float_as_uint(1.f / y);
+        }
+        // the determinant test of the triangle intersection, made on the reciprocal: every
+        // finite value, zero and subnormals included (an infinite determinant makes f zero
+        // and the distance zero or NaN, not a hit either way)
+        if (__builtin_fabsf(x) < __builtin_inff()) {
+            nc++;
+            nb += (__builtin_fabsf(x) < 0.0000001f) != !(__builtin_fabsf(r.x) <= 10000000.f);
+        }
+        if (__builtin_fabsf(y) < __builtin_inff()) {
+            nc++;
+            nb += (__builtin_fabsf(y) < 0.0000001f) != !(__builtin_fabsf(r.y) <= 10000000.f);
         }
         const v2f q = sqrt2_exact((v2f){x, y});
         if (x >= SQRT2_MIN && x <= SQRT2_MAX) {
