@@ -193,7 +193,7 @@ int rtx_device_count(void);
 /* Message for the calling thread's last failed call ("" if none). */
 const char *rtx_last_error(void);
 
-/* Device self-test with no counterpart in the reference.  Three arithmetic shortcuts of
+/* Device self-test with no counterpart in the reference.  The arithmetic shortcuts of
  * the kernels are compared with the plain IEEE evaluation they replace:
  *   out[0], out[1]  values checked / mismatches of the packed reciprocal against the
  *                   correctly rounded quotient 1.f / a (the reference's `f = 1.f / a`,

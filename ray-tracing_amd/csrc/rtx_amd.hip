@@ -716,6 +716,17 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (rs != RTX_OK) return rs;
         wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
     }
+#ifdef PHASE_TIMES
+    {
+        const unsigned long long *c = reinterpret_cast<const unsigned long long *>(s->h_ctr->pad1);
+        double sum = 0;
+        for (int k = 0; k < 10; k++) sum += (double)c[k];
+        fprintf(stderr, "sorted records, wave cycles by phase (%%): set-up %.1f  screen %.1f  cell masks %.1f  sort %.1f  "
+                        "pass set-up %.1f  candidate loop %.1f  shade %.1f  reduce %.1f   (total %.3g cycles)\n",
+                100 * c[0] / sum, 100 * c[1] / sum, 100 * c[2] / sum, 100 * c[3] / sum, 100 * c[4] / sum, 100 * c[5] / sum,
+                100 * c[6] / sum, 100 * c[7] / sum, sum);
+    }
+#endif
 #ifdef STEP_STATS
     {
         const unsigned long long *c = reinterpret_cast<const unsigned long long *>(s->h_ctr->pad1);

@@ -154,7 +154,7 @@ void shade_kernel(
     }
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
     if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
-#ifdef STEP_STATS
+#if defined(STEP_STATS) || defined(PHASE_TIMES)
     if (lane == 0)
         for (int k = 0; k < 10; k++) atomicAdd(reinterpret_cast<unsigned long long *>(ctr->pad1) + k, tot.st[k]);
 #endif

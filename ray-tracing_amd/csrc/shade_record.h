@@ -235,10 +235,21 @@ __device__ __forceinline__ float screen_segment(bool closed, f3 p0, f3 step, f3 
 struct ShadeTotals {
     uint32_t lit = 0, bounce_hits = 0;
     unsigned long long tests = 0, bounce_prims = 0;
-#ifdef STEP_STATS
+#if defined(STEP_STATS) || defined(PHASE_TIMES)
     unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 };
+// (measurement build only, -DPHASE_TIMES) wave cycles per phase of shade_record_sorted
+#ifdef PHASE_TIMES
+#define PHASE_MARK(k)                                                   \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        tot.st[k] += now_ - phase_t;                                    \
+        phase_t = now_;                                                 \
+    } while (0)
+#else
+#define PHASE_MARK(k)
+#endif
 #ifdef STEP_STATS
 // (measurement build only) why the rays of one candidate step fail
 __device__ __forceinline__ void step_stats(ShadeTotals &tot, const ray2 &r, const DPrim &p, bool live1, bool live2) {

@@ -284,6 +284,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         const float nl = (float)fr.n_lights;
         uint32_t lit_total = 0;
         unsigned long long tests_total = 0;
+#ifdef PHASE_TIMES
+        unsigned long long phase_t = __builtin_readcyclecounter();
+#endif
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
         const DPrim *__restrict__ leaf_prims = prims + rc.first;
@@ -304,7 +307,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             f3 o_first, o_last;
             const float margin = screen_segment(true, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
             const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
+            PHASE_MARK(0);
             n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane);
+            PHASE_MARK(1);
             use_sort = n_cand >= SORT_MIN_CAND;
 #ifdef STEP_STATS
             tot.st[8] += use_sort;
@@ -313,12 +318,14 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             if (use_sort) build_cell_masks(L, fan, leaf_prims, n_cand, lane);
         }
         wave_lds_sync();
+        PHASE_MARK(2);
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
         for (uint32_t chunk = 0; chunk < fr.n_lights; chunk += SORT_MAX) {
             const uint32_t n_chunk = min(fr.n_lights - chunk, (uint32_t)SORT_MAX);
             if (use_sort) sort_samples(L, lane, fr.seed, pixel, leaf, chunk, n_chunk);
+            PHASE_MARK(3);
             // a pass: entries base .. base + 127 of the sorted order, two per lane
             for (uint32_t base = 0; base < n_chunk; base += PASS_SAMPLES) {
                 const uint32_t last = n_chunk - 1;
@@ -368,6 +375,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                 // (no hit yet = +infinity: a hit at t = +inf, were there one, puts the point
                 // out of the scene, which lights the sample just as no hit does)
                 float tmin1 = __builtin_inff(), tmin2 = __builtin_inff();
+                PHASE_MARK(4);
                 if (n_list) {
                     tests_total += (unsigned long long)n_list * min(n_chunk - base, (uint32_t)PASS_SAMPLES);
                     uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)list[0]);
@@ -395,6 +403,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                         cur = nxt;
                     }
                 }
+                PHASE_MARK(5);
                 // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17)
                 const bool lit1 = live1 && (!(tmin1 < __builtin_inff()) || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
                 const bool lit2 = live2 && (!(tmin2 < __builtin_inff()) || out_of_scene(f3_add(p2, f3_scale(sd2, tmin2))));
@@ -411,6 +420,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                     }
                 }
                 wave_lds_sync();
+                PHASE_MARK(6);
             }
         }
         // sum over the lanes (fixed butterfly order, so a frame is reproducible)
@@ -425,4 +435,5 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
         tot.lit += lit_total;
         tot.tests += tests_total;
+        PHASE_MARK(7);
 }
