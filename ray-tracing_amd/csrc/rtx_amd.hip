@@ -721,7 +721,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         const unsigned long long *c = reinterpret_cast<const unsigned long long *>(s->h_ctr->pad1);
         double sum = 0;
         for (int k = 0; k < 10; k++) sum += (double)c[k];
-        fprintf(stderr, "sorted records, wave cycles by phase (%%): set-up %.1f  screen %.1f  cell masks %.1f  sort %.1f  "
+        fprintf(stderr, "hit records, wave cycles by phase (%%): set-up %.1f  screen %.1f  cell masks %.1f  sort %.1f  "
                         "pass set-up %.1f  candidate loop %.1f  shade %.1f  reduce %.1f   (total %.3g cycles)\n",
                 100 * c[0] / sum, 100 * c[1] / sum, 100 * c[2] / sum, 100 * c[3] / sum, 100 * c[4] / sum, 100 * c[5] / sum,
                 100 * c[6] / sum, 100 * c[7] / sum, sum);

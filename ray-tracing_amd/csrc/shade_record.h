@@ -295,6 +295,9 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float nl = (float)fr.n_lights;
         uint32_t lit_total = 0, bounce_hits = 0;
         unsigned long long bounce_prims = 0, tests_total = 0;
+#ifdef PHASE_TIMES
+        unsigned long long phase_t = __builtin_readcyclecounter();
+#endif
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
         const DPrim *__restrict__ leaf_prims = prims + rc.first;
@@ -329,6 +332,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float z_hi = (zl < o_zmin) ? o_zmax + margin : 3.0e38f;
         setup_planes(L, lane, o_first, o_last, zl);
         wave_lds_sync();
+        PHASE_MARK(0);
         // a leaf that fits the list is screened once, on the first pass
         const bool one_segment = count <= CAND_MAX;
         uint32_t n_cand = 0;
@@ -385,12 +389,14 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             // (no hit yet = +infinity: a hit at t = +inf, were there one, puts the point
                 // out of the scene, which lights the sample just as no hit does)
                 float tmin1 = __builtin_inff(), tmin2 = __builtin_inff();
+            PHASE_MARK(4);
             for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
                     n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
                                               z_lo, z_hi, margin);
                     wave_lds_sync();
+                    PHASE_MARK(1);
                 }
                 if (n_cand == 0) continue;
                 tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, (uint32_t)PASS_SAMPLES);
@@ -420,6 +426,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                     cur = nxt;
                 }
             }
+            PHASE_MARK(5);
             // lit unless something is hit inside [0, 1000]^3 (utils.h:12-17); the two
             // samples of a lane are added in sample order
             const bool lit1 = live1 && (!(tmin1 < __builtin_inff()) || out_of_scene(f3_add(p1, f3_scale(sd1, tmin1))));
@@ -437,6 +444,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                 }
             }
             wave_lds_sync();
+            PHASE_MARK(6);
         }
         // sum over the lanes (fixed butterfly order, so a frame is reproducible)
 #pragma unroll
@@ -447,6 +455,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             lit += __shfl_xor(lit, off);
         }
         lit_total += lit;
+        PHASE_MARK(7);
         if (lane == 0) L.level_sum[depth] = make_float4(acc.x, acc.y, acc.z, 0.f);
         if (!BOUNCE || depth >= fr.max_depth) break;
 
