@@ -143,13 +143,14 @@ __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_fi
         f3 m = f3_cross(da, db);
         const f3 dc = f3_make(500.f - o.x, 500.f - o.y, zl - o.z);
         if (f3_dot(m, dc) < 0.f) m = f3_scale(m, -1.f);
-        const float len = __builtin_sqrtf(f3_dot(m, m));
+        const float len2 = f3_dot(m, m);
         float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
         // Both start points must lie on the same side of the light plane: in between, the
         // pyramid turns inside out and "outside for both" says nothing about the others.
         const bool same_side = (zl > o_first.z && zl > o_last.z) || (zl < o_first.z && zl < o_last.z);
-        if (same_side && len > 1e-6f && len < 1e30f) {
-            m = f3_scale(m, 1.f / len);
+        if (same_side && len2 > 1e-12f && len2 < 1e30f) {
+            // (v_rsq_f32, 1 ulp: a screen's own rounding is covered by its margin)
+            m = f3_scale(m, __builtin_amdgcn_rsqf(len2));
             pl = make_float4(m.x, m.y, m.z, f3_dot(m, o));
         }
         L.plane[lane] = pl;
@@ -330,6 +331,20 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float o_zmin = fminf(o_first.z, o_last.z), o_zmax = fmaxf(o_first.z, o_last.z);
         const float z_lo = (zl > o_zmax) ? o_zmin - margin : -3.0e38f;
         const float z_hi = (zl < o_zmin) ? o_zmax + margin : 3.0e38f;
+#ifdef DUP_SETUP
+        { // (measurement build only) the per-record set-up a second time, on other values
+            f3 o2, d2;
+            primary_ray_uniform(fr, (pixel + 1) % fr.width, pixel / fr.width, lane, o2, d2);
+            f3 dlt2 = f3_make(0.f, 0.f, 0.f);
+            const f3 q0 = f3_add(p0, d2);
+            const bool c2 = acne_chain_delta3(lane, q0, step, fr.n_lights, dlt2);
+            f3 of2, ol2;
+            const float m2 = screen_segment(c2, q0, step, dlt2, nl, fr.cull_margin, of2, ol2);
+            asm volatile("" ::"v"(m2));
+            setup_planes(L, lane, of2, ol2, zl);
+            wave_lds_sync();
+        }
+#endif
         setup_planes(L, lane, o_first, o_last, zl);
         wave_lds_sync();
         PHASE_MARK(0);
@@ -393,6 +408,12 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
+#ifdef DUP_SCREEN
+                    n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
+                                              z_lo, z_hi, margin * 1.5f);
+                    asm volatile("" ::"s"(n_cand));
+                    wave_lds_sync();
+#endif
                     n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
                                               z_lo, z_hi, margin);
                     wave_lds_sync();
