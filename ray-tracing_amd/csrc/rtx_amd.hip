@@ -626,7 +626,17 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     const uint32_t shade_waves = p->max_depth ? SHADE_WAVES_PER_SIMD_BOUNCE
                                  : fr.sort_samples ? SHADE_WAVES_PER_SIMD_SORT
                                                    : SHADE_WAVES_PER_SIMD;
-    const uint32_t shade_blocks = (uint32_t)s->n_cu * shade_waves;
+    uint32_t shade_blocks = (uint32_t)s->n_cu * shade_waves;
+    // A frame with few hit records per resident wave (a small share of a frame split over
+    // several GPUs) ends with most SIMDs waiting for the last records; with fewer waves per
+    // SIMD every record finishes sooner and the kernel with it (measured on 1/4, 1/8 and 1/16 of
+    // the buddha frame: 5, 4-5 and 4 waves instead of 6 take 2, 6 and 17 % less).  The number
+    // of records is the previous frame's of this scene handle; the first frame takes the default.
+    if (fr.sort_samples && !p->max_depth && s->n_hits) {
+        const uint64_t per_wave = s->n_hits / ((uint64_t)s->n_cu * 4 * shade_waves);
+        if (per_wave < 4) shade_blocks = (uint32_t)s->n_cu * 4;
+        else if (per_wave < 14) shade_blocks = (uint32_t)s->n_cu * 5;
+    }
     const uint32_t merge_blocks = (uint32_t)((npix + MERGE_BLOCK - 1) / MERGE_BLOCK);
 
     uint64_t n_hits = 0;
@@ -720,7 +730,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     {
         const unsigned long long *c = reinterpret_cast<const unsigned long long *>(s->h_ctr->pad1);
         double sum = 0;
-        for (int k = 0; k < 10; k++) sum += (double)c[k];
+        for (int k = 0; k < 8; k++) sum += (double)c[k];
+        fprintf(stderr, "longest sorted record: %llu cycles (%llu candidates)\n", c[8], c[9]);
         fprintf(stderr, "hit records, wave cycles by phase (%%): set-up %.1f  screen %.1f  cell masks %.1f  sort %.1f  "
                         "pass set-up %.1f  candidate loop %.1f  shade %.1f  reduce %.1f   (total %.3g cycles)\n",
                 100 * c[0] / sum, 100 * c[1] / sum, 100 * c[2] / sum, 100 * c[3] / sum, 100 * c[4] / sum, 100 * c[5] / sum,

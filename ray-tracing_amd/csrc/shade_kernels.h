@@ -155,8 +155,15 @@ void shade_kernel(
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
     if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
 #if defined(STEP_STATS) || defined(PHASE_TIMES)
-    if (lane == 0)
-        for (int k = 0; k < 10; k++) atomicAdd(reinterpret_cast<unsigned long long *>(ctr->pad1) + k, tot.st[k]);
+    if (lane == 0) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(ctr->pad1);
+#ifdef PHASE_TIMES
+        for (int k = 0; k < 8; k++) atomicAdd(out + k, tot.st[k]);
+        if (atomicMax(out + 8, tot.st[8]) < tot.st[8]) out[9] = tot.st[9]; // (the longest record; racy, good enough)
+#else
+        for (int k = 0; k < 10; k++) atomicAdd(out + k, tot.st[k]);
+#endif
+    }
 #endif
     if (lane == 0 && tot.bounce_hits) {
         atomicAdd(&ctr->bounce_hits, (unsigned long long)tot.bounce_hits);

@@ -286,6 +286,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         unsigned long long tests_total = 0;
 #ifdef PHASE_TIMES
         unsigned long long phase_t = __builtin_readcyclecounter();
+        const unsigned long long record_t = phase_t;
 #endif
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
@@ -436,4 +437,10 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         tot.lit += lit_total;
         tot.tests += tests_total;
         PHASE_MARK(7);
+#ifdef PHASE_TIMES
+        if (phase_t - record_t > tot.st[8]) { // the longest record of this wave, and its candidates
+            tot.st[8] = phase_t - record_t;
+            tot.st[9] = n_cand;
+        }
+#endif
 }
