@@ -583,7 +583,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     fr.n_lights = p->n_lights;
     fr.max_depth = p->max_depth;
     fr.wide_dets = s->wide_dets;
-    fr.sort_samples = (p->max_depth == 0 && p->n_lights >= SORT_MIN_LIGHTS && !(p->flags & RTX_FLAG_NO_SORT)) ? 1u : 0u;
+    fr.sort_samples = (p->n_lights >= SORT_MIN_LIGHTS && !(p->flags & RTX_FLAG_NO_SORT)) ? 1u : 0u;
     fr.seed = p->seed;
     fr.acne = p->acne;
     fr.cull_margin = screen_margin(s, p);
@@ -623,16 +623,15 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
     const uint32_t trace_blocks = (uint32_t)s->n_cu * TRACE_BLOCKS_PER_CU;
-    const uint32_t shade_waves = p->max_depth ? SHADE_WAVES_PER_SIMD_BOUNCE
-                                 : fr.sort_samples ? SHADE_WAVES_PER_SIMD_SORT
-                                                   : SHADE_WAVES_PER_SIMD;
+    const uint32_t shade_waves = fr.sort_samples ? SHADE_WAVES_PER_SIMD_SORT : SHADE_WAVES_PER_SIMD;
     uint32_t shade_blocks = (uint32_t)s->n_cu * shade_waves;
+    const uint32_t bounce_blocks = (uint32_t)s->n_cu * SHADE_WAVES_PER_SIMD_BOUNCE;
     // A frame with few hit records per resident wave (a small share of a frame split over
     // several GPUs) ends with most SIMDs waiting for the last records; with fewer waves per
     // SIMD every record finishes sooner and the kernel with it (measured on 1/4, 1/8 and 1/16 of
     // the buddha frame: 5, 4-5 and 4 waves instead of 6 take 2, 6 and 17 % less).  The number
     // of records is the previous frame's of this scene handle; the first frame takes the default.
-    if (fr.sort_samples && !p->max_depth && s->n_hits) {
+    if (fr.sort_samples && s->n_hits) {
         const uint64_t per_wave = s->n_hits / ((uint64_t)s->n_cu * 4 * shade_waves);
         if (per_wave < 4) shade_blocks = (uint32_t)s->n_cu * 4;
         else if (per_wave < 14) shade_blocks = (uint32_t)s->n_cu * 5;
@@ -674,11 +673,11 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
                 fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr);                    \
     } while (0)
 #define LAUNCH_SHADE(B, I, W)                                                                                \
-    shade_kernel<B, I, W><<<shade_blocks, SHADE_BLOCK, 0, st>>>(fr, s->d_prims, s->d_mats, wb.recs,       \
-                                                                wb.rec_cap, wb.colors, wb.ctr)
+    shade_kernel<B, I, W><<<(B) ? bounce_blocks : shade_blocks, SHADE_BLOCK, 0, st>>>(                       \
+        fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr)
         const uint32_t nlg = p->n_lights;
         const bool ieee = (p->flags & RTX_FLAG_IEEE_SHADE) != 0;
-        const bool few = p->max_depth == 0 && nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
+        const bool few = nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
         if (!few)
             classify_kernel<<<few_blocks, 256, 0, st>>>(fr, wb.recs, wb.rec_cap, wb.colors, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
@@ -690,13 +689,22 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             else if (nlg <= 8) LAUNCH_FEW(8);
             else if (nlg <= 16) LAUNCH_FEW(16);
             else LAUNCH_FEW(32);
-        } else if (p->max_depth == 0 && fr.sort_samples) {
+        } else if (fr.sort_samples) {
             if (ieee) LAUNCH_SHADE(false, true, SHADE_WAVES_PER_SIMD_SORT);
             else LAUNCH_SHADE(false, false, SHADE_WAVES_PER_SIMD_SORT);
-        } else if (p->max_depth == 0) {
+        } else {
             if (ieee) LAUNCH_SHADE(false, true, SHADE_WAVES_PER_SIMD);
             else LAUNCH_SHADE(false, false, SHADE_WAVES_PER_SIMD);
-        } else {
+        }
+        if (p->max_depth) {
+            // Mirror bounces (raytracing.h:51-61): the kernel above has added every primary hit's
+            // own light samples.  bounce_find_kernel lists the records whose reflected ray hits
+            // something in its leaf (a few in a hundred), and the bounce build of the shading
+            // kernel adds the deeper levels of those.  The work lists start again from empty.
+            HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(wb.ctr) + offsetof(DCounters, cls), 0,
+                                   offsetof(DCounters, tiles) - offsetof(DCounters, cls), st));
+            bounce_find_kernel<<<few_blocks, 256, 0, st>>>(fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors,
+                                                           wb.ctr);
             if (ieee) LAUNCH_SHADE(true, true, SHADE_WAVES_PER_SIMD_BOUNCE);
             else LAUNCH_SHADE(true, false, SHADE_WAVES_PER_SIMD_BOUNCE);
         }

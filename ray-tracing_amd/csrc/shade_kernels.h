@@ -143,11 +143,10 @@ void shade_kernel(
     for (uint32_t step = 0; step < N_CLASSES; step++) {
         const uint32_t w = step >> 1; // weight group; within it plain before sorted
         const uint32_t cls = (step & 1u) ? CLASS_SORTED + w : CLASS_PLAIN + w;
-        if (cls < CLASS_PLAIN) {
-            if constexpr (!BOUNCE)
-                drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted,
-                                              lane, tot);
-        } else {
+        if (cls < CLASS_PLAIN && !BOUNCE) {
+            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted, lane,
+                                          tot);
+        } else { // (the kernel of the mirror bounces takes every list the same way)
             drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
                                             tot);
         }
@@ -171,13 +170,85 @@ void shade_kernel(
     }
 }
 
+// ---- mirror bounces: which records have one ---------------------------------------
+// With max_depth > 0 every primary hit reflects its ray (raytracing.h:51-61), but the bounce
+// is traced inside the hit's own leaf and only a few in a hundred hit anything there.  One
+// lane per record: the end of the acne chain, the reflected ray and the leaf's primitives
+// exactly as shade_record<true> computes them, and the records whose bounce hits something
+// (or whose Fresnel weight is not finite, so that "weight times black" is not zero) go
+// to the work list that the kernel of the deeper levels drains.  The others keep the colour
+// of their own samples.
+__global__ __launch_bounds__(256) void bounce_find_kernel(DFrame fr, const DPrim *__restrict__ prims,
+                                                          const DMat *__restrict__ mats,
+                                                          const DRec *__restrict__ recs, uint32_t rec_cap,
+                                                          float4 *__restrict__ colors,
+                                                          DCounters *__restrict__ ctr) {
+    const RecMap map = rec_map(ctr, rec_cap); // final: written by the trace kernel
+    const uint32_t n_recs = map.total;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t *__restrict__ list = work_list(colors, rec_cap, CLASS_PLAIN);
+    for (uint32_t base = wave_id * 64; base < n_recs; base += n_waves * 64) {
+        const uint32_t i = base + lane;
+        bool want = false;
+        uint32_t ridx = 0;
+        if (i < n_recs) {
+            ridx = rec_index(map, i);
+            const DRec *rc = recs + ridx;
+            const uint32_t pixel = rc->pixel, count = rc->count;
+            const DPrim *__restrict__ leaf_prims = prims + rc->first;
+            const f3 nrm = f3_make(rc->nx, rc->ny, rc->nz);
+            const f3 p0 = f3_make(rc->px, rc->py, rc->pz);
+            f3 o, d;
+            primary_ray(fr, pixel % fr.width, pixel / fr.width, o, d);
+            const f3 step = f3_scale(nrm, fr.acne);
+            // where the bounce starts: the hit position after all the acne steps (closed form
+            // only if all three components have one, as in shade_record)
+            f3 dlt = f3_make(0.f, 0.f, 0.f), pos = p0;
+            const bool cx = acne_chain_delta(p0.x, step.x, fr.n_lights, dlt.x);
+            const bool cy = acne_chain_delta(p0.y, step.y, fr.n_lights, dlt.y);
+            const bool cz = acne_chain_delta(p0.z, step.z, fr.n_lights, dlt.z);
+            if (fr.n_lights && cx && cy && cz) {
+                const float sn = (float)fr.n_lights;
+                pos = f3_make(p0.x + sn * dlt.x, p0.y + sn * dlt.y, p0.z + sn * dlt.z);
+            } else {
+                for (uint32_t k = 0; k < fr.n_lights; k++) pos = f3_add(pos, step);
+            }
+            const f3 n2 = f3_scale(nrm, 2.f); // reflect(), vec3.h:103-106
+            const f3 rd = f3_normalize(f3_sub(d, f3_scale(n2, f3_dot(nrm, d))));
+            const f3 ro = f3_add(pos, f3_scale(rd, fr.acne));
+            const float fres = rdm_fresnel(f3_dot(rd, nrm), mats[rc->mat]);
+            want = !(__builtin_fabsf(fres) < __builtin_inff());
+            for (uint32_t kk = 0; kk < count && !want; kk++) {
+                const DPrim *pp = leaf_prims + kk;
+                float t;
+                if ((pp->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
+                    want = tri_hit(ro, rd, pp->a, pp->b, pp->c, t);
+                else
+                    want = sph_hit(ro, rd, pp->a, pp->b.y, t);
+            }
+        }
+        const unsigned long long mask = __ballot(want);
+        if (mask) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(&ctr->cls[CLASS_PLAIN].count, (uint32_t)__popcll(mask));
+            first = __builtin_amdgcn_readfirstlane(first);
+            if (want)
+                list[first + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = ridx;
+        }
+    }
+}
+
 // ---- shadow + shade for few light samples ---------------------------------------
 // With n_lights <= G <= 32 (the reference as committed uses 1) a wave per hit record
 // would leave most lanes idle, so here a wave takes 64 / G records at once: lane
 // l handles sample l % G of record l / G, walks that record's leaf on its own (vector
 // loads, next primitive in flight) and the G lanes of a record are summed with the
 // same butterfly the one-record kernel uses, so both kernels return identical colours.
-// No mirror bounces (max_depth = 0 only).
+// The primary hits' own samples only: in a frame with mirror bounces the deeper levels are
+// added afterwards by the bounce build of shade_kernel.
 template <uint32_t G, bool IEEE>
 __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,

@@ -66,11 +66,14 @@
 // Register budget of shade_kernel: 5 waves per SIMD (96 VGPRs).  Measured on buddha
 // 3840x2160 / 500 samples: 4 waves (the compiler's own choice, 110 VGPRs) 5.12 ms,
 // 5 waves 4.87 ms, 6 waves 4.86 ms with three times the scratch traffic.  The build
-// with mirror bounces keeps the compiler's 3 waves (158 VGPRs) rather than spill.
+// with mirror bounces keeps the compiler's 3 waves (167 VGPRs) rather than spill (it sees
+// only the few records whose bounce hits something; 4..6 waves: within 4 %).
 #ifndef SHADE_WAVES_PER_SIMD
 #define SHADE_WAVES_PER_SIMD 5
 #endif
+#ifndef SHADE_WAVES_PER_SIMD_BOUNCE
 #define SHADE_WAVES_PER_SIMD_BOUNCE 3
+#endif
 // Frames whose records are shaded with sorted samples (SORT_MIN_LIGHTS samples or more): 6 waves
 // (80 VGPRs).  Measured in round 2 with 5 / 4 / 6 waves: buddha 4K/500 3.14 / 3.28 / 3.07 ms, the
 // multi-mesh frame 36.5 / 38.4 / 35.7, dino 2.37 / 2.38 / 2.37, bunny (100 samples, unsorted)
@@ -354,9 +357,16 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
+        // (BOUNCE build: the samples of the primary hit have been added by the kernel without
+        // bounces that ran before; this one starts from that sum and adds the deeper levels)
+        const bool level_done = BOUNCE && depth == 0;
+        if (level_done && !closed && lane < 3) { // only the end of the chain is needed: where the bounce starts
+            for (uint32_t sidx = 0; sidx < fr.n_lights; sidx++) run = run + inc;
+            if (fr.n_lights) L.chain[((fr.n_lights - 1) % PASS_SAMPLES) * 3 + lane] = run;
+        }
         // Each pass takes 128 samples: lane l owns samples base + l and base + 64 + l and
         // carries both rays through the triangle tests as packed pairs.
-        for (uint32_t base = 0; base < fr.n_lights; base += PASS_SAMPLES) {
+        for (uint32_t base = 0; !level_done && base < fr.n_lights; base += PASS_SAMPLES) {
             const bool second = base + 64 < fr.n_lights; // wave-uniform: any sample in the upper half?
             const uint32_t k1 = base + lane, k2 = k1 + 64;
             const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
@@ -477,7 +487,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         }
         lit_total += lit;
         PHASE_MARK(7);
-        if (lane == 0) L.level_sum[depth] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (lane == 0) L.level_sum[depth] = level_done ? colors[ridx] : make_float4(acc.x, acc.y, acc.z, 0.f);
         if (!BOUNCE || depth >= fr.max_depth) break;
 
         // ---- mirror bounce (raytracing.h:53-60) ----

@@ -8,7 +8,7 @@ and a sampler seed, renders a small frame on both sides and requires: the same h
 records (ids, distance bits), the same number of lit samples (every occlusion decision),
 RGB within 1/255 on >= 99.9 % of the pixels, per-record colours within 5e-3 of
 |channel| + 0.01 + a thousandth of the record's largest channel.  Where the GPU adds the
-samples of a record in index order (mirror bounces, fewer than 129 samples,
+samples of a record in index order (fewer than 129 samples,
 RTX_FLAG_NO_SORT) the oracle adds them in the GPU's order (ORC_FLAG_WAVE_SUM) and the
 bound is 5e-4: what is left is the fast build of the BSDF.  With sorted samples the order
 differs, and with the light inside the scene or a negative acne offset contributions of both
@@ -94,7 +94,7 @@ for case in range(n_cases):
     if n_parts > 1:
         p.stripe_rows, p.n_parts, p.part = stripe_rows, n_parts, part
     # the oracle adds a record's samples in the GPU's order where the GPU's order is fixed
-    in_order = max_depth > 0 or nl < 129 or (flags & capi.RTX_FLAG_NO_SORT) != 0
+    in_order = nl < 129 or (flags & capi.RTX_FLAG_NO_SORT) != 0
     q = capi.Params.from_buffer_copy(p)
     if in_order:
         q.flags |= op.ORC_FLAG_WAVE_SUM

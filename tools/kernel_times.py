@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times of a workload, frame by frame (GPU box).
-usage: kernel_times.py [workload ...] [--frames N] [--ieee] [--parts N (render part 0 of N row-stripe parts)]"""
+usage: kernel_times.py [workload ...] [--frames N] [--ieee] [--parts N (render part 0 of N row-stripe parts)]
+                       [--depth D (mirror bounces, raytracing.h:18 MAX_DEPTH)]"""
 import importlib
 import os
 import sys
@@ -14,6 +15,7 @@ import bench  # noqa: E402
 
 frames = 8
 parts = 1
+depth = 0
 flags = 0
 names = []
 args = sys.argv[1:]
@@ -23,6 +25,8 @@ while args:
         frames = int(args.pop(0))
     elif a == "--parts":
         parts = int(args.pop(0))
+    elif a == "--depth":
+        depth = int(args.pop(0))
     elif a == "--ieee":
         flags |= rtx.capi.RTX_FLAG_IEEE_SHADE
     else:
@@ -38,6 +42,7 @@ for name in names or ["bunny", "buddha"]:
     for k in range(frames):
         p = rtx.default_params(w, h, nl, 1)
         p.flags |= flags
+        p.max_depth = depth
         if parts > 1:
             p.stripe_rows, p.n_parts, p.part = 8, parts, 0
         t0 = time.perf_counter()
