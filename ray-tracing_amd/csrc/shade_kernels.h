@@ -73,12 +73,12 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
 // starts on the head of its block (blocks b and b + 8 tend to share an XCD, hence an L2)
 // and moves on when it is drained; heads only ever advance, so a wave that has seen all
 // of them drained is done with the list.
-template <bool SORTED, bool BOUNCE, bool IEEE, typename Lds>
+template <bool SORTED, bool BOUNCE, bool IEEE>
 __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const DPrim *__restrict__ prims,
                                            const DMat *__restrict__ mats, const DRec *__restrict__ recs,
                                            uint32_t rec_cap, float4 *__restrict__ colors,
-                                           DCounters *__restrict__ ctr, Lds &L, uint32_t lane,
-                                           ShadeTotals &tot) {
+                                           DCounters *__restrict__ ctr, ShadeLds &LP, SortLds &LS, BounceLds &B,
+                                           uint32_t lane, ShadeTotals &tot) {
     const uint32_t n = ctr->cls[cls].count; // final: written by classify_kernel
     if (n == 0) return;
     const uint32_t *__restrict__ list = work_list(colors, rec_cap, cls);
@@ -114,9 +114,9 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
             if (e >= n) break;
             const uint32_t ridx = list[e];
             if constexpr (SORTED)
-                shade_record_sorted<IEEE>(fr, prims, mats, recs, colors, L, lane, ridx, tot);
+                shade_record_sorted<IEEE>(fr, prims, mats, recs, colors, LS, lane, ridx, tot);
             else
-                shade_record<BOUNCE, IEEE>(fr, prims, mats, recs, colors, L, lane, ridx, tot);
+                shade_record<BOUNCE, IEEE>(fr, prims, mats, recs, colors, LP, LS, B, lane, ridx, tot);
         }
     }
 }
@@ -133,6 +133,7 @@ void shade_kernel(
         ShadeLds plain;
         SortLds sorted;
     } lds[SHADE_WAVES];
+    __shared__ BounceLds levels[BOUNCE ? SHADE_WAVES : 1]; // (one unused entry in the build without bounces)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     ShadeTotals tot;
     // Long records first, and the most numerous list last: the plain records with a large
@@ -144,11 +145,11 @@ void shade_kernel(
         const uint32_t w = step >> 1; // weight group; within it plain before sorted
         const uint32_t cls = (step & 1u) ? CLASS_SORTED + w : CLASS_PLAIN + w;
         if (cls < CLASS_PLAIN && !BOUNCE) {
-            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].sorted, lane,
-                                          tot);
+            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain,
+                                          lds[wave].sorted, levels[0], lane, tot);
         } else { // (the kernel of the mirror bounces takes every list the same way)
-            drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain, lane,
-                                            tot);
+            drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain,
+                                            lds[wave].sorted, levels[BOUNCE ? wave : 0], lane, tot);
         }
     }
     if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);

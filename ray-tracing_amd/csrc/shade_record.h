@@ -119,9 +119,13 @@ __device__ __forceinline__ uint32_t *work_list(float4 *colors, uint32_t rec_cap,
     return reinterpret_cast<uint32_t *>(colors + rec_cap) + (size_t)cls * rec_cap;
 }
 
-struct ShadeLds {
+// (bounce build only, beside the per-wave LDS of the sampling paths)
+struct BounceLds {
     float4 level_sum[MAX_BOUNCES + 2];    // per bounce level: sum of its light samples
     float4 level_weight[MAX_BOUNCES + 1]; // specular * Fresnel of the level's hit
+};
+
+struct ShadeLds {
     float chain[PASS_SAMPLES * 3];
     float4 plane[8];
     uint16_t cand[CAND_MAX];
@@ -291,11 +295,22 @@ __device__ __forceinline__ void step_stats(ShadeTotals &tot, const ray2 &r, cons
 }
 #endif
 
+struct SortLds;
+template <bool IEEE>
+__device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
+                                                     uint32_t count, uint32_t pixel, uint32_t leaf, const DMat &mat,
+                                                     f3 nrm, f3 p0, f3 view, uint32_t k_off, SortLds &L,
+                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out);
+
+// One hit record with its light samples in index order; the BOUNCE build adds the levels
+// of the mirror bounces (raytracing.h:51-61) to the stored sum of the primary level.  LS:
+// the wave's LDS for a level with sorted samples (it overlaps L), B: where the bounce build
+// keeps the levels' sums and weights (neither is touched by the build without bounces).
 template <bool BOUNCE, bool IEEE>
 __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__restrict__ prims,
                                              const DMat *__restrict__ mats, const DRec *__restrict__ recs,
-                                             float4 *__restrict__ colors, ShadeLds &L, uint32_t lane,
-                                             uint32_t ridx, ShadeTotals &tot) {
+                                             float4 *__restrict__ colors, ShadeLds &L, SortLds &LS, BounceLds &B,
+                                             uint32_t lane, uint32_t ridx, ShadeTotals &tot) {
         const float nl = (float)fr.n_lights;
         uint32_t lit_total = 0, bounce_hits = 0;
         unsigned long long bounce_prims = 0, tests_total = 0;
@@ -324,6 +339,14 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
 #ifdef STEP_STATS
         tot.st[9] += !closed;
 #endif
+        // (BOUNCE build: the samples of the primary hit have been added by the kernel without
+        // bounces that ran before; this one starts from that sum and adds the deeper levels)
+        const bool level_done = BOUNCE && depth == 0;
+        // a deeper level whose leaf and start points allow it takes the samples sorted by light
+        // cell, as the primary levels of such records do
+        bool level_sorted = false;
+        if constexpr (BOUNCE)
+            level_sorted = depth > 0 && fr.sort_samples && closed && count >= SORT_MIN_LEAF && count <= CAND_MAX;
         float run = lane == 0 ? p0.x : lane == 1 ? p0.y : p0.z;
         const float inc = lane == 0 ? step.x : lane == 1 ? step.y : step.z;
 
@@ -348,7 +371,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             wave_lds_sync();
         }
 #endif
-        setup_planes(L, lane, o_first, o_last, zl);
+        if (!level_done && !level_sorted) setup_planes(L, lane, o_first, o_last, zl);
         wave_lds_sync();
         PHASE_MARK(0);
         // a leaf that fits the list is screened once, on the first pass
@@ -357,16 +380,21 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
-        // (BOUNCE build: the samples of the primary hit have been added by the kernel without
-        // bounces that ran before; this one starts from that sum and adds the deeper levels)
-        const bool level_done = BOUNCE && depth == 0;
+        if (level_sorted) {
+            uint32_t lit_s = 0;
+            const float4 sum = shade_level_sorted<IEEE>(fr, leaf_prims, count, pixel, leaf, mat, nrm, p0, view, k_off, LS,
+                                                        lane, tot, lit_s);
+            acc = f3_make(sum.x, sum.y, sum.z);
+            lit = lit_s;
+            wave_lds_sync();
+        }
         if (level_done && !closed && lane < 3) { // only the end of the chain is needed: where the bounce starts
             for (uint32_t sidx = 0; sidx < fr.n_lights; sidx++) run = run + inc;
             if (fr.n_lights) L.chain[((fr.n_lights - 1) % PASS_SAMPLES) * 3 + lane] = run;
         }
         // Each pass takes 128 samples: lane l owns samples base + l and base + 64 + l and
         // carries both rays through the triangle tests as packed pairs.
-        for (uint32_t base = 0; !level_done && base < fr.n_lights; base += PASS_SAMPLES) {
+        for (uint32_t base = 0; !level_done && !level_sorted && base < fr.n_lights; base += PASS_SAMPLES) {
             const bool second = base + 64 < fr.n_lights; // wave-uniform: any sample in the upper half?
             const uint32_t k1 = base + lane, k2 = k1 + 64;
             const bool live1 = k1 < fr.n_lights, live2 = k2 < fr.n_lights;
@@ -477,18 +505,25 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             wave_lds_sync();
             PHASE_MARK(6);
         }
-        // sum over the lanes (fixed butterfly order, so a frame is reproducible)
+        // sum over the lanes (fixed butterfly order, so a frame is reproducible; a level with
+        // sorted samples comes back summed)
+        if (!level_sorted) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            lit += __shfl_xor(lit, off);
+            for (int off = 32; off >= 1; off >>= 1) {
+                acc.x += __shfl_xor(acc.x, off);
+                acc.y += __shfl_xor(acc.y, off);
+                acc.z += __shfl_xor(acc.z, off);
+                lit += __shfl_xor(lit, off);
+            }
         }
         lit_total += lit;
         PHASE_MARK(7);
-        if (lane == 0) L.level_sum[depth] = level_done ? colors[ridx] : make_float4(acc.x, acc.y, acc.z, 0.f);
-        if (!BOUNCE || depth >= fr.max_depth) break;
+        if constexpr (!BOUNCE) { // one level: its sum is the record's colour
+            if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            break;
+        }
+        if (lane == 0) B.level_sum[depth] = level_done ? colors[ridx] : make_float4(acc.x, acc.y, acc.z, 0.f);
+        if (depth >= fr.max_depth) break;
 
         // ---- mirror bounce (raytracing.h:53-60) ----
         // the reflected ray starts from the hit position after all the acne steps
@@ -506,7 +541,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float fres = rdm_fresnel(f3_dot(rd, nrm), mat);
         if (lane == 0) {
             const f3 w = f3_scale(mat.spec, fres);
-            L.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);
+            B.level_weight[depth] = make_float4(w.x, w.y, w.z, 0.f);
         }
         // nearest hit of the reflected ray in the leaf: lanes over the primitives, then
         // the smallest distance wins, the earliest primitive on ties (intersect.h:120-128)
@@ -538,7 +573,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         bt = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bt)));
         depth++;
         if (bk == RTXD_NONE) { // the bounce leaves the leaf: it contributes black
-            if (lane == 0) L.level_sum[depth] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane == 0) B.level_sum[depth] = make_float4(0.f, 0.f, 0.f, 0.f);
             break;
         }
         bounce_hits++;
@@ -553,16 +588,18 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         } // bounce loop
         // colour of the primary hit = its own samples + weight * colour of the bounce, folded
         // from the deepest level (ret = color + specular * Fresnel * color_reflect, :60)
-        wave_lds_sync();
-        if (lane == 0) {
-            float4 c = L.level_sum[depth];
-            for (uint32_t lv = depth; lv-- > 0;) {
-                const float4 sm = L.level_sum[lv], w = L.level_weight[lv];
-                c = make_float4(sm.x + w.x * c.x, sm.y + w.y * c.y, sm.z + w.z * c.z, 0.f);
+        if constexpr (BOUNCE) {
+            wave_lds_sync();
+            if (lane == 0) {
+                float4 c = B.level_sum[depth];
+                for (uint32_t lv = depth; lv-- > 0;) {
+                    const float4 sm = B.level_sum[lv], w = B.level_weight[lv];
+                    c = make_float4(sm.x + w.x * c.x, sm.y + w.y * c.y, sm.z + w.z * c.z, 0.f);
+                }
+                colors[ridx] = c;
             }
-            colors[ridx] = c;
+            wave_lds_sync();
         }
-        wave_lds_sync();
         tot.lit += lit_total;
         tot.tests += tests_total;
         tot.bounce_hits += bounce_hits;

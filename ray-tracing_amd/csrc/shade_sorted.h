@@ -274,29 +274,23 @@ __device__ __forceinline__ void sort_samples(SortLds &L, uint32_t lane, uint32_t
     wave_lds_sync();
 }
 
-// One hit record with sorted light samples (see above).  Needs n_lights >= 1, a leaf of at
-// most CAND_MAX primitives and the closed form of all three origin components.
+// One level of a hit record with sorted light samples (see above): the hit at p0 with
+// normal nrm and material mat, seen along -view, in the leaf leaf_prims[0 .. count); its
+// samples have the sampler's indices k_off .. k_off + n_lights - 1.  Needs n_lights >= 1,
+// a leaf of at most CAND_MAX primitives and the closed form of all three origin components.
+// Returns the sum of the samples' contributions (raytracing.h:36-50), the same value in
+// every lane, and the number of lit samples.
 template <bool IEEE>
-__device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPrim *__restrict__ prims,
-                                                    const DMat *__restrict__ mats,
-                                                    const DRec *__restrict__ recs, float4 *__restrict__ colors,
-                                                    SortLds &L, uint32_t lane, uint32_t ridx, ShadeTotals &tot) {
+__device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
+                                                     uint32_t count, uint32_t pixel, uint32_t leaf, const DMat &mat,
+                                                     f3 nrm, f3 p0, f3 view, uint32_t k_off, SortLds &L,
+                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out) {
         const float nl = (float)fr.n_lights;
-        uint32_t lit_total = 0;
         unsigned long long tests_total = 0;
 #ifdef PHASE_TIMES
         unsigned long long phase_t = __builtin_readcyclecounter();
         const unsigned long long record_t = phase_t;
 #endif
-        const DRec rc = recs[ridx];
-        const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
-        const DPrim *__restrict__ leaf_prims = prims + rc.first;
-        const DMat mat = mats[rc.mat];
-        const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
-        const f3 p0 = f3_make(rc.px, rc.py, rc.pz);
-        f3 o, d;
-        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
-        const f3 view = f3_scale(d, -1.f);      // raytracing.h:47
         const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
         f3 dlt = f3_make(0.f, 0.f, 0.f);        // origin of sample k = p0 + (k + 1) * dlt
         acne_chain_delta3(lane, p0, step, fr.n_lights, dlt);
@@ -325,7 +319,7 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         uint32_t lit = 0;
         for (uint32_t chunk = 0; chunk < fr.n_lights; chunk += SORT_MAX) {
             const uint32_t n_chunk = min(fr.n_lights - chunk, (uint32_t)SORT_MAX);
-            if (use_sort) sort_samples(L, lane, fr.seed, pixel, leaf, chunk, n_chunk);
+            if (use_sort) sort_samples(L, lane, fr.seed, pixel, leaf, k_off + chunk, n_chunk);
             PHASE_MARK(3);
             // a pass: entries base .. base + 127 of the sorted order, two per lane
             for (uint32_t base = 0; base < n_chunk; base += PASS_SAMPLES) {
@@ -350,9 +344,9 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
                     wave_lds_sync();
                 } else { // few candidates: samples in index order, every candidate in every pass
                     uint32_t ux, uy;
-                    light_sample_u(fr.seed, pixel, leaf, chunk + s1, ux, uy);
+                    light_sample_u(fr.seed, pixel, leaf, k_off + chunk + s1, ux, uy);
                     w1 = ux | (uy << 9);
-                    light_sample_u(fr.seed, pixel, leaf, chunk + s2, ux, uy);
+                    light_sample_u(fr.seed, pixel, leaf, k_off + chunk + s2, ux, uy);
                     w2 = ux | (uy << 9);
                 }
 
@@ -432,9 +426,6 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             acc.z += __shfl_xor(acc.z, off);
             lit += __shfl_xor(lit, off);
         }
-        lit_total += lit;
-        if (lane == 0) colors[ridx] = make_float4(acc.x, acc.y, acc.z, 0.f);
-        tot.lit += lit_total;
         tot.tests += tests_total;
         PHASE_MARK(7);
 #ifdef PHASE_TIMES
@@ -443,4 +434,25 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
             tot.st[9] = n_cand;
         }
 #endif
+        lit_out = lit;
+        return make_float4(acc.x, acc.y, acc.z, 0.f);
+}
+
+// One hit record with sorted light samples: its primary level, to colors[ridx].
+template <bool IEEE>
+__device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPrim *__restrict__ prims,
+                                                    const DMat *__restrict__ mats,
+                                                    const DRec *__restrict__ recs, float4 *__restrict__ colors,
+                                                    SortLds &L, uint32_t lane, uint32_t ridx, ShadeTotals &tot) {
+        const DRec rc = recs[ridx];
+        const uint32_t pixel = rc.pixel;
+        const DMat mat = mats[rc.mat];
+        f3 o, d;
+        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
+        uint32_t lit = 0;
+        const float4 sum = shade_level_sorted<IEEE>(fr, prims + rc.first, rc.count, pixel, rc.leaf, mat,
+                                                    f3_make(rc.nx, rc.ny, rc.nz), f3_make(rc.px, rc.py, rc.pz),
+                                                    f3_scale(d, -1.f) /* raytracing.h:47 */, 0u, L, lane, tot, lit);
+        if (lane == 0) colors[ridx] = sum;
+        tot.lit += lit;
 }
