@@ -8,9 +8,9 @@ A step is one frame of the workload: the image rows are dealt to the N ranks in 
 ABI (rtx_render_device) into device memory, and the stripes are gathered to rank 0 over
 RCCL.  The scene is uploaded once before the timed region.  --inflight frames are in flight
 at a time per GPU (default: 1 on one GPU, so that the per-kernel times of the roofline
-block are those of a kernel that has the GPU to itself; 2 on several GPUs, where a rank's
-share of the frame is small and the gather and the kernels' last waves overlap with the next
-frame's kernels on separate HIP streams); every timed frame is complete, gathered and
+block are those of a kernel that has the GPU to itself; 2 on two or three GPUs and 3 on four
+or more, where a rank's share of the frame is small and the gather and the kernels' last
+waves overlap with the next frames' kernels on separate HIP streams); every timed frame is complete, gathered and
 assembled before the clock stops.  Rank 0 prints one JSON line:
 
   value     Mrays/s = (primary rays + shadow rays) of the whole frame / frame time, both
@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="buddha", choices=sorted(WORKLOADS))
     ap.add_argument("--inflight", type=int, default=0,
-                    help="frames in flight per GPU; 0 (default) = 1 on one GPU, 2 on several (own scene replica, stream and output tile each); with 2 "
+                    help="frames in flight per GPU; 0 (default) = 1 on one GPU, 2 on two or three, 3 on more (own scene replica, stream and output tile each); with 2 "
                          "the kernels of consecutive frames overlap: more frames per second, but a kernel's "
                          "HIP-event duration then includes the time it shares the GPU, so the roofline "
                          "figures are only meaningful with 1")
@@ -212,7 +212,10 @@ def main():
     # in frame order, so all ranks issue their collectives in the same order.  With more than
     # one slot a frame's low-occupancy phases (the trace kernel's heaviest tiles, the last
     # records of the shading kernel, the gather) overlap with the next frame's kernels.
-    n_slots = args.inflight if args.inflight > 0 else (1 if world == 1 else 2)
+    # (measured on one GPU rendering its share of the buddha frame, tools/share_rate.py: half the
+    # frame 1.53 / 1.41 / 1.40 ms per frame with 1 / 2 / 3 in flight, a quarter 0.92 / 0.84 / 0.78, an
+    # eighth 0.58 / 0.48 / 0.45)
+    n_slots = args.inflight if args.inflight > 0 else (1 if world == 1 else 2 if world < 4 else 3)
     replicas = [rtx.Scene(desc, local_rank) for _ in range(n_slots)]
     # (one slot: everything on the current stream, which also orders tile reuse)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [torch.cuda.current_stream()]
