@@ -75,7 +75,7 @@
 #define SHADE_WAVES_PER_SIMD_BOUNCE 3
 #endif
 // Frames whose records are shaded with sorted samples (SORT_MIN_LIGHTS samples or more): 6 waves
-// (80 VGPRs).  Measured in round 2 with 5 / 4 / 6 waves: buddha 4K/500 3.14 / 3.28 / 3.07 ms, the
+// (80 VGPRs).  Measured with 5 / 4 / 6 waves: buddha 4K/500 3.14 / 3.28 / 3.07 ms, the
 // multi-mesh frame 36.5 / 38.4 / 35.7, dino 2.37 / 2.38 / 2.37, bunny (100 samples, unsorted)
 // 0.625 / 0.604 / 0.656.
 #ifndef SHADE_WAVES_PER_SIMD_SORT
