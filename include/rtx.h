@@ -218,7 +218,10 @@ uint32_t rtx_part_rows(const rtx_params *p);
 /* Scene -----------------------------------------------------------------------
  * Replaces the in-memory `Boxs` argument of render_image (raytracing.h:100):
  * validates the description, converts it to the device layout and uploads it
- * to HIP device `device`.  The description is not referenced after return. */
+ * to HIP device `device`.  The description is not referenced after return.
+ * The first scene created on a device in a process runs rtx_selftest there (about
+ * 50 ms) and fails with RTX_ERR_NO_DEVICE if the device's arithmetic does not
+ * reproduce the IEEE results the kernels' shortcuts rely on. */
 typedef struct rtx_scene rtx_scene;
 rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, rtx_scene **out);
 void rtx_scene_destroy(rtx_scene *scene);

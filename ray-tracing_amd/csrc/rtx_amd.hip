@@ -164,6 +164,28 @@ extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) {
     return RTX_OK;
 }
 
+// The kernels' exact arithmetic shortcuts (reciprocal, square root, division, determinant
+// threshold) start from the hardware's v_rcp_f32 / v_rsq_f32 and are exact because of what
+// those return on gfx950, as rtx_selftest establishes value by value.  Hit ids that are
+// silently off on a part that rounds differently would be worse than no result: the first
+// scene created on a device runs the self-test there (some 50 ms) and refuses the device
+// if anything mismatches.
+static std::mutex g_check_mutex;
+static int g_checked[SCRATCH_MAX_DEVICES]; // 0 not yet, 1 passed, 2 failed
+static rtx_status arithmetic_check(int device) {
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return RTX_OK;
+    std::lock_guard<std::mutex> lock(g_check_mutex);
+    if (g_checked[device] == 0) {
+        uint64_t out[7];
+        if (rtx_status rs = rtx_selftest(device, out); rs != RTX_OK) return rs;
+        g_checked[device] = (out[1] == 0 && out[3] == 0 && out[6] == 0) ? 1 : 2;
+    }
+    if (g_checked[device] == 2)
+        return fail(RTX_ERR_NO_DEVICE, "the device's arithmetic self-test found mismatches with the IEEE results "
+                                       "(see rtx_selftest): refusing to render on it");
+    return RTX_OK;
+}
+
 extern "C" void rtx_params_default(rtx_params *p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));
@@ -372,6 +394,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
     if (rtx_status rs = scratch_resolve(device); rs != RTX_OK) return rs;
+    if (rtx_status rs = arithmetic_check(device); rs != RTX_OK) return rs;
 
     rtx_scene *s = new rtx_scene();
     s->device = device;
