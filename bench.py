@@ -67,6 +67,16 @@ def hbm_traffic(workload):
         return None
 
 
+def valu_utilization(workload):
+    """Share of the shading kernel's cycles in which its SIMDs issue vector instructions, from the SQ
+    counters of a separate rocprofv3 pass (profiles/hbm_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            return json.load(f)["valu_issue_utilization"].get(workload)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_scene(rtx, scenes, name):
     """Scene description through the product's host layer (C++), not the oracle."""
     host = importlib.import_module("ray-tracing_amd.host_py")
@@ -349,6 +359,10 @@ def main():
                 "units_per_launch": {"prim_tests_run": int(st.shadow_tests_run), "shadow_rays": int(st.shadow_rays),
                                      "shaded_samples": int(st.lit_samples)},
                 "tests_run_fraction": st.shadow_tests_run / max(st.shadow_tests, 1),
+                # measured, not derived from the FLOP count: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the
+                # kernel (tools/hbm_traffic.py; good to a few per cent).  Near 1 = the kernel is bound by
+                # vector issue slots; frac then measures how many of them are the counted FLOP
+                "valu_issue_utilization": valu_utilization(args.workload),
                 # what the reference's algorithm would have done for the same rays (every leaf
                 # primitive tested for every shadow ray): a speed-up equivalent, not a hardware rate
                 "algorithmic_equivalent": {

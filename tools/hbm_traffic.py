@@ -10,6 +10,10 @@ import re
 import sys
 
 
+N_SIMDS = 1024  # 256 CUs x 4
+N_SQ = 32       # 8 XCDs x 4 shader engines, one SQ_BUSY_CYCLES counter each
+
+
 def last_shade(path, counter):
     val = None
     for line in open(path):
@@ -39,6 +43,18 @@ def main():
         out["fetch_kb"][w], out["write_kb"][w] = f, wr
         out["shade_kernel"][w] = int((f + wr) * 1024)
         out["shade_kernel_upper"][w] = int((2 * f + wr) * 1024)
+        # vector-issue utilisation of the same kernel from the SQ pass: SQ_ACTIVE_INST_VALU (quad-cycles,
+        # summed over the SIMDs) against SQ_BUSY_CYCLES (cycles, summed over the 32 shader engines' SQs)
+        try:
+            act = last_shade("%s/pmc_sq_%s.txt" % (src, w), "SQ_ACTIVE_INST_VALU")
+            busy = last_shade("%s/pmc_sq_%s.txt" % (src, w), "SQ_BUSY_CYCLES")
+            dur = last_shade("%s/pmc_sq_%s.txt" % (src, w), "_dur_ms")
+        except OSError:
+            act = busy = dur = None
+        if act and busy:
+            out.setdefault("valu_issue_utilization", {})[w] = round((act * 4 / N_SIMDS) / (busy / N_SQ), 4)
+            if dur:
+                out.setdefault("shader_clock_ghz", {})[w] = round(busy / N_SQ / (dur * 1e-3) / 1e9, 3)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["shade_kernel"]))
 
