@@ -136,13 +136,28 @@ def spawn_ranks(n):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     children = []
+    # a rank that hangs (a peer that never joins the rendezvous, a collective one rank never
+    # enters) must end the job with an error, not block the caller for ever: every rank dumps
+    # its Python stacks to stderr shortly before the limit, then all are terminated
+    limit = float(os.environ.get("RTX_BENCH_TIMEOUT", "1500"))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RTX_BENCH_STACKS_AFTER=str(max(limit - 10.0, 1.0)))
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc, live = 0, list(children)
+    t_start = time.monotonic()
     while live:
         time.sleep(0.05)
+        if time.monotonic() - t_start > limit:
+            print("bench.py: ranks still running after %.0f s, terminating them" % limit, file=sys.stderr, flush=True)
+            for c in live:
+                c.terminate()
+            for c in live:
+                try:
+                    c.wait(10)
+                except subprocess.TimeoutExpired:
+                    c.kill()
+            return 124
         for c in list(live):
             code = c.poll()
             if code is None:
@@ -179,6 +194,15 @@ def main():
         # the N ranks.  It has not touched the GPU (nor imported torch) at this point.
         raise SystemExit(spawn_ranks(args.gpus))
 
+    if "RTX_BENCH_STACKS_AFTER" in os.environ:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RTX_BENCH_STACKS_AFTER"]), exit=False)
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        # all ranks are on this node: bind gloo to the loopback interface instead of whatever
+        # the host name resolves to (it may not resolve at all, or only after a long time-out)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+
     import torch
     import torch.distributed as dist
 
@@ -192,7 +216,6 @@ def main():
     # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (not a measurement):
     # RTX_BENCH_SHARE_GPU=1 puts rank r on GPU r % device_count, RTX_BENCH_BACKEND=gloo
     # replaces RCCL, which refuses two ranks on one device.
-    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
     if os.environ.get("RTX_BENCH_SHARE_GPU") == "1":
         local_rank %= torch.cuda.device_count()
     elif world > 1 and torch.cuda.device_count() == 1:

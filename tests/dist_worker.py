@@ -21,6 +21,7 @@ capi = op.capi
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = sys.argv[1]
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # all ranks are on this host
     w, h, nl, seed, stripe = 160, 90, 3, 5, 8
     dist.init_process_group("gloo", rank=rank, world_size=world)
     b = op.OracleBuilder(6)

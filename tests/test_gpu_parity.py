@@ -673,26 +673,6 @@ def test_bench_line_and_frames_in_flight():
     assert json.loads(out.stdout.strip().splitlines()[-1])["config"]["frames_in_flight"] == 2
 
 
-def test_bench_starts_its_own_ranks():
-    """`python bench.py --gpus 2` with nothing else: the process starts its two ranks itself
-    (one per GPU on a multi-GPU node; here both share the box's GPU and talk over gloo,
-    a rehearsal of the path, not a measurement) and rank 0 prints the line."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RTX_BENCH_BACKEND="gloo", RTX_BENCH_SHARE_GPU="1")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "bunny",
-                          "--steps", "3", "--warmup", "1", "--verify"], capture_output=True, text=True,
-                         timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["value"] > 0
-    assert "verify slot 0: assembled frame equals" in out.stderr
-
-
 @pytest.mark.gpu
 def test_collectives_of_the_bench_run_over_rccl():
     """The calls bench.py and FrameGather make on several GPUs, over RCCL itself (one rank:
