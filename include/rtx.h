@@ -242,8 +242,11 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
 
 /* rtx_render_device for callers that cannot allocate.  No counterpart in the
  * reference: it exists for callers that may not call hipMalloc / hipFree
- * while they render (code under HIP graph capture, tight serving loops,
- * harnesses that forbid allocation).  Same arguments, same kernels and the
+ * while they render (tight serving loops, harnesses that forbid allocation,
+ * processes whose device memory is fully committed).  Like rtx_render_device
+ * it synchronises `hip_stream` before it returns (the frame's counters are
+ * read back), so it cannot be recorded into a HIP graph: a capturing stream
+ * makes the call fail with RTX_ERR_HIP.  Same arguments, same kernels and the
  * same output bytes as rtx_render_device, but every per-frame work buffer
  * (hit records, their colours and work lists, one record head per pixel,
  * tile queues, counters) is carved from a static device array of

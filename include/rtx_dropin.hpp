@@ -16,7 +16,9 @@
 // the functions are implemented from scratch in ray-tracing_amd/host/.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -28,6 +30,32 @@ struct Vec3 {
     T x, y, z;
 };
 using Vec3F = Vec3<float>;
+
+// The operators and free functions of vec3.h:9-112, for callers that assemble their own
+// scene with them.  Evaluation order is part of the contract (the products of dot are added
+// left to right, normalize is three divisions by the norm, reflect is I - N * 2.f * dot(N, I)
+// with the scalings applied one after the other): compiled like the reference (no
+// -ffast-math, no contraction) they return the same bits.  `<` and `>` hold when ALL three
+// components compare that way (a partial order; vec3.h:91-101).
+template <typename T> inline float dot(const Vec3<T> &a, const Vec3<T> &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> inline float dot2(const Vec3<T> &v) { return dot(v, v); }
+template <typename T> inline float norm(const Vec3<T> &v) { return std::sqrt(dot2(v)); }
+template <typename T> inline bool operator==(const Vec3<T> &a, const Vec3<T> &b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+template <typename T> inline bool operator!=(const Vec3<T> &a, const Vec3<T> &b) { return a.x != b.x || a.y != b.y || a.z != b.z; }
+template <typename T> inline Vec3<T> operator+(const Vec3<T> &a, const Vec3<T> &b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> inline Vec3<T> operator-(const Vec3<T> &a, const Vec3<T> &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> inline Vec3<T> operator*(const Vec3<T> &a, const Vec3<T> &b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename T> inline Vec3<T> operator/(const Vec3<T> &a, const Vec3<T> &b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+template <typename T> inline Vec3<T> operator*(const Vec3<T> &a, const float &s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> inline Vec3<T> operator/(const Vec3<T> &a, const float &s) { return {a.x / s, a.y / s, a.z / s}; }
+template <typename T> inline bool operator>(const Vec3<T> &a, const Vec3<T> &b) { return a.x > b.x && a.y > b.y && a.z > b.z; }
+template <typename T> inline bool operator<(const Vec3<T> &a, const Vec3<T> &b) { return a.x < b.x && a.y < b.y && a.z < b.z; }
+template <typename T> inline Vec3<T> normalize(const Vec3<T> &v) { return v / norm(v); }
+template <typename T> inline Vec3<T> cross(const Vec3<T> &u, const Vec3<T> &v) {
+    return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+inline Vec3F reflect(const Vec3F &I, const Vec3F &N) { return I - N * 2.f * dot(N, I); }
+template <typename T> inline void print(const Vec3<T> &v) { std::printf("%.1f %.1f %.1f\n", v.x, v.y, v.z); }
 
 // ---- structs.h --------------------------------------------------------------------------
 enum Type { SPHERE = 1, TRIANGLE };
@@ -64,6 +92,15 @@ struct Light {
     Vec3F color;
 };
 
+// What the reference's intersect_* functions fill in (structs.h:45-51).  The GPU path keeps
+// its hits in its own records; the type is here for callers that name it.
+struct Intersection {
+    Object object;
+    Vec3F position;
+    float distance;
+    Vec3F normale;
+};
+
 struct Mesh {
     Vec3F position;
     float taille;
@@ -81,6 +118,7 @@ struct Box {
 
 typedef std::vector<Box> Boxs;
 typedef std::vector<Object> Objects;
+typedef std::vector<Intersection> Intersections;
 
 // ---- settings the reference fixes with #define ---------------------------------------------
 #ifndef DEPTH_BOX
@@ -102,6 +140,9 @@ struct Settings {
     uint32_t stripe_rows = 8;       // rows per stripe of that split
     std::string output = "out.png"; // raytracing.h:140
     bool quiet = false;             // suppress the progress / "saved" messages
+    bool keep_replicas = true;      // keep the uploaded scene between render calls (see
+                                    // replica_stats); false = free it before the call returns,
+                                    // as the reference holds nothing after render_image
     Settings();
 };
 Settings &settings();
@@ -130,9 +171,14 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
 
 // render_image / render_to_memory keep what they uploaded: one scene replica per entry of
 // settings().devices (or one on settings().device), reused by later calls as long as the
-// flattened scene has the same content, so that a caller rendering the same `Boxs` again
-// (other frame size, sample count, camera ...) pays neither the conversion to the device
-// layout nor the upload again.  created / reused count replicas since the process started;
+// flattened scene has the same content (compared array by array with a copy kept on the
+// host), so that a caller rendering the same `Boxs` again (other frame size, sample count,
+// camera ...) pays neither the conversion to the device layout nor the upload again.  What
+// stays allocated until release_replicas() or the end of the process: per device the scene
+// (64 B per leaf primitive reference), the work buffers of its largest frame (96 B per hit
+// record, 4 B per pixel) and the page-locked rows of a split frame; on the host one copy of
+// the flattened scene (48 B per leaf primitive reference).  settings().keep_replicas = false
+// turns the keeping off.  created / reused count replicas since the process started;
 // release_replicas() frees them (call it before the process ends if the HIP runtime must
 // see every free).
 void replica_stats(uint64_t *created, uint64_t *reused);

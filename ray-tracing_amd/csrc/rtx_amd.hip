@@ -72,7 +72,7 @@ static unsigned char *g_scratch_ptr[SCRATCH_MAX_DEVICES]; // per device: address
 
 // Resolves the address of `device`'s copy of the work area, once.  The device must be current.
 static rtx_status scratch_resolve(int device) {
-    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return RTX_OK; // no static work area on this device
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return fail(RTX_ERR_LIMIT, "device index beyond the library's table of 64 devices");
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (g_scratch_ptr[device]) return RTX_OK;
     unsigned char *ptr = nullptr;
@@ -173,7 +173,7 @@ extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) {
 static std::mutex g_check_mutex;
 static int g_checked[SCRATCH_MAX_DEVICES]; // 0 not yet, 1 passed, 2 failed
 static rtx_status arithmetic_check(int device) {
-    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return RTX_OK;
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return fail(RTX_ERR_LIMIT, "device index beyond the library's table of 64 devices");
     std::lock_guard<std::mutex> lock(g_check_mutex);
     if (g_checked[device] == 0) {
         uint64_t out[7];
@@ -808,7 +808,11 @@ extern "C" rtx_status rtx_render_device_static(rtx_scene *s, const rtx_params *p
     if (!d_rgb) return fail(RTX_ERR_INVALID, "null output");
     rtx_status rs = check_params(s, p);
     if (rs != RTX_OK) return rs;
-    unsigned char *base = (s->device >= 0 && s->device < SCRATCH_MAX_DEVICES) ? g_scratch_ptr[s->device] : nullptr;
+    unsigned char *base = nullptr;
+    if (s->device >= 0 && s->device < SCRATCH_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        base = g_scratch_ptr[s->device];
+    }
     if (!base) return fail(RTX_ERR_NO_DEVICE, "no static work area was resolved for the scene's device");
     const uint32_t rows = rtx_part_rows(p);
     const uint64_t npix = (uint64_t)rows * p->width;

@@ -392,6 +392,7 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             for (uint32_t sidx = 0; sidx < fr.n_lights; sidx++) run = run + inc;
             if (fr.n_lights) L.chain[((fr.n_lights - 1) % PASS_SAMPLES) * 3 + lane] = run;
         }
+        if (level_done && !closed) wave_lds_sync(); // every lane reads the three components at the bounce
         // Each pass takes 128 samples: lane l owns samples base + l and base + 64 + l and
         // carries both rays through the triangle tests as packed pairs.
         for (uint32_t base = 0; !level_done && !level_sorted && base < fr.n_lights; base += PASS_SAMPLES) {

@@ -372,7 +372,7 @@ struct Replica {
 
 struct ReplicaCache {
     uint64_t key = 0;
-    size_t sizes[4] = {0, 0, 0, 0};
+    FlatScene content; // what the replicas were uploaded from (a hash match is confirmed on it)
     bool valid = false;
     std::vector<Replica> slots;
     uint64_t created = 0, reused = 0;
@@ -391,6 +391,20 @@ uint64_t content_key(const FlatScene &f) {
     h = fnv1a(h, f.prims.data(), f.prims.size() * sizeof(rtx_prim));
     h = fnv1a(h, f.materials.data(), f.materials.size() * sizeof(rtx_material));
     return fnv1a(h, &f.light, sizeof(f.light));
+}
+
+// Element-wise equality of two flattened scenes (the structs are made of 4-byte fields
+// without padding, so comparing their bytes compares their fields).
+template <typename T>
+bool same_array(const std::vector<T> &a, const std::vector<T> &b) {
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+}
+bool same_content(const FlatScene &a, const FlatScene &b) {
+    static_assert(sizeof(rtx_node) == 32 && sizeof(rtx_leaf) == 8 && sizeof(rtx_prim) == 48 &&
+                      sizeof(rtx_material) == 32 && sizeof(rtx_light) == 24,
+                  "no padding in the flattened scene's structs");
+    return same_array(a.nodes, b.nodes) && same_array(a.leaves, b.leaves) && same_array(a.prims, b.prims) &&
+           same_array(a.materials, b.materials) && std::memcmp(&a.light, &b.light, sizeof(rtx_light)) == 0;
 }
 
 void free_slot(Replica &r) {
@@ -429,6 +443,7 @@ void replica_stats(uint64_t *created, uint64_t *reused) {
 void release_replicas() {
     for (Replica &r : g_replicas.slots) free_slot(r);
     g_replicas.slots.clear();
+    g_replicas.content = FlatScene();
     g_replicas.valid = false;
 }
 
@@ -438,15 +453,22 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
     FlatScene flat;
     if (!flatten(light, boxs, cfg.box_depth, flat, error)) return false;
     const rtx_scene_desc d = flat.desc();
-    // another scene than last time: the replicas are of no use any more
+    // another scene than last time: the replicas are of no use any more (the hash only
+    // saves the comparison when the scenes differ; a match is confirmed array by array)
     const uint64_t key = content_key(flat);
-    const size_t sizes[4] = {flat.nodes.size(), flat.leaves.size(), flat.prims.size(), flat.materials.size()};
-    if (!g_replicas.valid || g_replicas.key != key || std::memcmp(sizes, g_replicas.sizes, sizeof(sizes)) != 0) {
+    if (!g_replicas.valid || g_replicas.key != key || !same_content(flat, g_replicas.content)) {
         release_replicas();
         g_replicas.key = key;
-        std::memcpy(g_replicas.sizes, sizes, sizeof(sizes));
+        g_replicas.content = flat;
         g_replicas.valid = true;
     }
+    // (keep_replicas = false: this call's replicas are released before it returns)
+    struct ReleaseAtExit {
+        bool on;
+        ~ReleaseAtExit() {
+            if (on) release_replicas();
+        }
+    } release_at_exit{!cfg.keep_replicas};
     rtx_params p = cfg.frame;
     p.stripe_rows = p.n_parts = p.part = 0;
     rgb.assign((size_t)p.width * p.height * 3, 0);

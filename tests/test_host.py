@@ -198,3 +198,90 @@ def test_mesh_files_hold_what_parse_reads_from_the_reference(host, scenes):
         assert rc == 0
         v0, f0 = scenes.load_mesh(name)
         assert np.array_equal(v.view(np.uint32), v0.view(np.uint32)) and np.array_equal(f, f0)
+
+
+DROPIN_SNIPPET = r'''
+#include "rtx_dropin.hpp"
+#include <cstdio>
+#include <cstdlib>
+// a caller that assembles its own values with the reference's vector operators
+int main(int argc, char **argv) {
+    if (argc != 4) return 2;
+    const int n = std::atoi(argv[3]);
+    FILE *in = std::fopen(argv[1], "rb"), *out = std::fopen(argv[2], "wb");
+    if (!in || !out) return 3;
+    for (int k = 0; k < n; k++) {
+        Vec3F v;
+        if (std::fread(&v, sizeof(v), 1, in) != 1) return 4;
+        const Vec3F u = normalize(v);
+        const Vec3F w = {v.z, v.x, v.y};
+        const Vec3F r = reflect(u, normalize(w));
+        const Vec3F c = cross(v, w);
+        const Vec3F mix = (v + w) * 0.5f - (v * w) / 3.f + v / w;
+        const float s[4] = {dot(v, w), dot2(v), norm(v), (v < w ? 1.f : 0.f) + (v > w ? 2.f : 0.f) +
+                                                          (v == w ? 4.f : 0.f) + (v != w ? 8.f : 0.f)};
+        std::fwrite(&u, sizeof(u), 1, out);
+        std::fwrite(&r, sizeof(r), 1, out);
+        std::fwrite(&c, sizeof(c), 1, out);
+        std::fwrite(&mix, sizeof(mix), 1, out);
+        std::fwrite(s, sizeof(s), 1, out);
+    }
+    Intersections hits;
+    Intersection hit = Intersection();
+    hit.distance = 1.f;
+    hit.normale = Vec3F{0.f, 0.f, 1.f};
+    hit.object.type = SPHERE;
+    hits.push_back(hit);
+    std::fclose(out);
+    return hits.size() == 1 && sizeof(Intersection) == 100 ? 0 : 5; // structs.h:45-51: 72 + 12 + 4 + 12 bytes
+}
+'''
+
+
+def test_vector_operators_of_the_drop_in_header(op, golden_dir, tmp_path):
+    """vec3.h:9-112 and structs.h:45-51,74 as the drop-in header carries them: a C++11
+    caller that uses the operators compiles, normalize() returns the bits the reference's
+    normalize returned for the committed known-answer inputs, and the other functions
+    follow the reference's evaluation order (checked against a binary32 restatement, and
+    reflect also against the reference's own function where its harness is built)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kat = np.load(os.path.join(golden_dir, "kat_functions.npz"))
+    v = np.ascontiguousarray(kat["normalize_in"], dtype=np.float32)
+    (tmp_path / "snippet.cpp").write_text(DROPIN_SNIPPET)
+    v.tofile(str(tmp_path / "in.bin"))
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-Wall", "-Wextra", "-I",
+                           os.path.join(root, "include"), str(tmp_path / "snippet.cpp"), "-o", str(tmp_path / "snippet")])
+    subprocess.check_call([str(tmp_path / "snippet"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(len(v))])
+    got = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float32).reshape(len(v), 16)
+    f = np.float32
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    assert np.array_equal(bits(got[:, 0:3]), bits(kat["normalize_out"]))
+    # binary32 restatement, operation by operation
+    with np.errstate(all="ignore"):
+        w = v[:, [2, 0, 1]]
+        dot_ = lambda a, b: (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+        nrm = lambda a: a / np.sqrt(dot_(a, a))[:, None]
+        u, n = nrm(v), nrm(w)
+        refl = u - (n * f(2.0)) * dot_(n, u)[:, None]
+        cr = np.stack([v[:, 1] * w[:, 2] - v[:, 2] * w[:, 1], v[:, 2] * w[:, 0] - v[:, 0] * w[:, 2],
+                       v[:, 0] * w[:, 1] - v[:, 1] * w[:, 0]], axis=1)
+        mix = ((v + w) * f(0.5) - (v * w) / f(3.0)) + v / w
+        lt, gt = (v < w).all(axis=1), (v > w).all(axis=1)
+        eq = (v == w).all(axis=1)
+        flags = lt * f(1) + gt * f(2) + eq * f(4) + (~eq) * f(8)
+    assert np.array_equal(bits(got[:, 3:6]), bits(refl))
+    assert np.array_equal(bits(got[:, 6:9]), bits(cr))
+    assert np.array_equal(bits(got[:, 9:12]), bits(mix))
+    assert np.array_equal(bits(got[:, 12]), bits(dot_(v, w)))
+    assert np.array_equal(bits(got[:, 13]), bits(dot_(v, v)))
+    assert np.array_equal(bits(got[:, 14]), bits(np.sqrt(dot_(v, v))))
+    assert np.array_equal(got[:, 15], flags)
+    if op.have_ref():   # the reference's own reflect (vec3.h:103-106)
+        import ctypes as C
+        ref = op.ref()
+        F3 = C.c_float * 3
+        for k in range(0, len(v), 7):
+            o = F3()
+            ref.ref_reflect(F3(*u[k]), F3(*n[k]), o)
+            assert np.array_equal(bits(np.array(list(o), dtype=np.float32)), bits(got[k, 3:6]))
