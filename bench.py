@@ -43,6 +43,8 @@ WORKLOADS = {
     "multi": ("multi", 3840, 2160, 1000,
               "bunny + dino + buddha + sphere, 3840x2160, 1000 light samples (BASELINE.json configs[4])"),
     "default": ("default", 1000, 1000, 1, "scene.h as committed, 1000x1000, 1 light sample"),
+    "default_500": ("default", 1000, 1000, 500,
+                    "scene.h as committed, 1000x1000, 500 light samples (the frame README.md:11 quotes at '~ 1 minute')"),
 }
 STRIPE_ROWS = 8
 
@@ -57,24 +59,52 @@ PEAK_FP32_UNFUSED_TFLOPS = 78.6   # the same issue rate without FMA contraction
 PEAK_HBM_GBS = 8000.0
 
 
-def hbm_traffic(workload):
-    """HBM bytes of one shade_kernel launch as measured with rocprofv3 PMC passes (a
-    separate run; see profiles/hbm_traffic.json), or None when not measured."""
+def counters_file(rtx, workload):
+    """What the rocprofv3 PMC passes of a separate run measured for one shade_kernel launch of
+    this workload (profiles/hbm_traffic.json, written by tools/hbm_traffic.py): HBM bytes and
+    the share of the kernel's cycles in which its SIMDs issue vector instructions.  The file
+    names the kernel sources it was measured on; for other sources the figures would describe
+    another kernel and are not quoted.  Returns (traffic, valu_issue_utilization, note)."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            return json.load(f)["shade_kernel"].get(workload)
-    except (OSError, KeyError, ValueError):
-        return None
+            data = json.load(f)
+    except (OSError, ValueError):
+        return None, None, "profiles/hbm_traffic.json not found"
+    measured_on = data.get("kernel_source_sha256")
+    if measured_on != rtx.kernel_source_hash():
+        return None, None, ("profiles/hbm_traffic.json was measured on other kernel sources (%s...), not quoted; "
+                            "tools/profile_round.sh refreshes it" % str(measured_on)[:12])
+    return (data.get("shade_kernel", {}).get(workload), data.get("valu_issue_utilization", {}).get(workload),
+            "rocprofv3 --pmc passes of a separate run on the same kernel sources (sha256 %s...)" % measured_on[:12])
 
 
-def valu_utilization(workload):
-    """Share of the shading kernel's cycles in which its SIMDs issue vector instructions, from the SQ
-    counters of a separate rocprofv3 pass (profiles/hbm_traffic.json), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            return json.load(f)["valu_issue_utilization"].get(workload)
-    except (OSError, KeyError, ValueError):
+def rt_main_cold(scenes):
+    """The reference's own use: one process, one frame of the committed scene (main.cpp:14-31),
+    through the command-line renderer: wall time of the process, and the compute time it
+    prints (init of the runtime, scene conversion, upload, frame, read-back, PNG)."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "ray-tracing_amd", "host", "rt_main")
+    if not os.path.exists(exe):
         return None
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "meshs"))
+        for name in ("bunny", "dino"):
+            v, f = scenes.load_mesh(name)
+            with open(os.path.join(d, "meshs", name + ".off"), "w") as fh:
+                fh.write("OFF\n%d %d 0\n" % (len(v), len(f)))
+                fh.write("".join("%.9g %.9g %.9g\n" % tuple(float(x) for x in p) for p in v))
+                fh.write("".join("3 %d %d %d \n" % tuple(int(x) for x in t) for t in f))
+        t0 = time.perf_counter()
+        out = subprocess.run([exe], cwd=d, capture_output=True, text=True, timeout=300)
+        wall = (time.perf_counter() - t0) * 1e3
+        m = re.search(r"Compute time \(ms\): ([0-9.]+)", out.stdout)
+        if out.returncode != 0 or not m:
+            return {"error": (out.stderr or out.stdout)[-200:]}
+        return {"process_ms": wall, "compute_ms": float(m.group(1)),
+                "what": "rt_main, scene.h as committed, 1000x1000, 1 light sample, out.png written; compute_ms is "
+                        "what it prints for render_image (main.cpp:17-31), process_ms the whole process"}
 
 
 def build_scene(rtx, scenes, name):
@@ -249,7 +279,16 @@ def main():
     # frame 1.53 / 1.41 / 1.40 ms per frame with 1 / 2 / 3 in flight, a quarter 0.92 / 0.84 / 0.78, an
     # eighth 0.58 / 0.48 / 0.45)
     n_slots = args.inflight if args.inflight > 0 else (1 if world == 1 else 2 if world < 4 else 3)
+    # cold path: the first scene of the process on this device (code object load, sampled
+    # arithmetic self-test, conversion, upload) and a second one (conversion and upload only)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first_scene = rtx.Scene(desc, local_rank)
+    create_first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
     replicas = [rtx.Scene(desc, local_rank) for _ in range(n_slots)]
+    create_again_ms = (time.perf_counter() - t0) * 1e3 / n_slots
+    first_scene.close()
     # (one slot: everything on the current stream, which also orders tile reuse)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_slots)] if n_slots > 1 else [torch.cuda.current_stream()]
     gathers = [tiles.FrameGather(torch, dist, h, w, STRIPE_ROWS, world, rank, dev) for _ in range(n_slots)]
@@ -262,8 +301,16 @@ def main():
             streams[slot].wait_event(tile_free[slot])
         return replicas[slot].render_device(p, gathers[slot].tile.data_ptr(), streams[slot].cuda_stream)
 
+    gather_events = []
+
     def exchange(slot):
+        if world > 1:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         gathers[slot].run()   # RCCL gather to rank 0 + scatter of the stripes into the frame
+        if world > 1:
+            ev1.record()
+            gather_events.append((ev0, ev1))
         if n_slots > 1:
             tile_free[slot] = torch.cuda.Event()
             tile_free[slot].record()
@@ -294,12 +341,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the first frame of a scene handle (work buffers allocated, perhaps grown and the frame
+    # rendered again), then the second
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st_first = render(0)
+    exchange(0)
+    fence()
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    render(0)
+    exchange(0)
+    fence()
+    second_frame_ms = (time.perf_counter() - t0) * 1e3
+
     run_frames(args.warmup)
     fence()
+    del gather_events[:]
     t0 = time.perf_counter()
     frames = run_frames(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    # the exchange step on the stream it runs on (gather + scatter of the stripes into the frame)
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)
     st = frames[-1]
     trace_ms = sum(f.kernel_ms[0] for f in frames)
     shade_ms = sum(f.kernel_ms[1] for f in frames)
@@ -307,12 +371,19 @@ def main():
     counts = torch.tensor([elapsed, float(st.primary_rays), float(st.shadow_rays), float(st.shadow_tests),
                            float(st.hits), float(st.lit_samples), float(st.shadow_tests_run)],
                           dtype=torch.float64, device=dev)
+    # per rank, for the slowest-rank columns of an N > 1 line
+    per_rank = torch.tensor([trace_ms / args.steps, shade_ms / args.steps, merge_ms / args.steps, gather_ms,
+                             float(st.hits)], dtype=torch.float64, device=dev)
+    rank_max, rank_min = per_rank.clone(), per_rank.clone()
     if world > 1:
         mx = counts.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         counts[0] = mx[0]
+        dist.all_reduce(rank_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rank_min, op=dist.ReduceOp.MIN)
     elapsed, primary, shadow, tests, hits, lit, tests_run = [float(x) for x in counts.tolist()]
+    rank_max, rank_min = rank_max.tolist(), rank_min.tolist()
 
     ranks_seen = dist.get_world_size() if world > 1 else 1
     # the same frames through rtx_render (host output buffer: the PCIe read-back is part of
@@ -346,7 +417,7 @@ def main():
         flop_run = (st.shadow_tests_run * FLOP_PER_PRIM_TEST + st.shadow_rays * FLOP_PER_SHADOW_RAY +
                     st.lit_samples * FLOP_PER_SHADED_SAMPLE)
         achieved = flop_run / sec / 1e12 if sec > 0 else 0.0
-        traffic = hbm_traffic(args.workload)
+        traffic, valu_issue, counters_note = counters_file(rtx, args.workload)
         out = {
             "metric": "Mrays/s (primary+shadow)",
             "value": rays / (elapsed / args.steps) / 1e6,
@@ -354,6 +425,8 @@ def main():
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_host": host_ms,
+            # the same frame timed through rtx_render: host output buffer, PCIe read-back included
+            "value_host": (rays / (host_ms * 1e-3) / 1e6) if host_ms else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -385,7 +458,8 @@ def main():
                 # measured, not derived from the FLOP count: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the
                 # kernel (tools/hbm_traffic.py; good to a few per cent).  Near 1 = the kernel is bound by
                 # vector issue slots; frac then measures how many of them are the counted FLOP
-                "valu_issue_utilization": valu_utilization(args.workload),
+                "valu_issue_utilization": valu_issue,
+                "counters_note": counters_note,
                 # what the reference's algorithm would have done for the same rays (every leaf
                 # primitive tested for every shadow ray): a speed-up equivalent, not a hardware rate
                 "algorithmic_equivalent": {
@@ -401,7 +475,23 @@ def main():
                                 "/ launch time: the scene is cache resident, HBM is not the bound"},
             },
             "kernel_ms": {"trace": trace_ms / k, "shade": shade_avg_ms, "merge": merge_ms / k},
+            # cold path of this process (rank 0): scene creation and the first frames of a handle
+            "cold": {"scene_create_first_ms": create_first_ms, "scene_create_again_ms": create_again_ms,
+                     "first_minus_again_ms": create_first_ms - create_again_ms,
+                     "first_minus_again_is": "code object load, sampled arithmetic self-test, address of the static work area",
+                     "first_frame_ms": first_frame_ms, "first_frame_attempts": int(st_first.render_attempts),
+                     "second_frame_ms": second_frame_ms, "record_capacity": int(st_first.record_capacity)},
         }
+        if world > 1:
+            # slowest and fastest rank, per frame: a poor scaling point shows here whether it is the
+            # kernels of the heaviest share, the spread between the shares, or the exchange step
+            names = ("trace_ms", "shade_ms", "merge_ms", "gather_ms", "hit_records")
+            out["ranks"] = {"max": dict(zip(names, rank_max)), "min": dict(zip(names, rank_min)),
+                            "note": "per-frame averages over the timed steps; kernel times are HIP events on the "
+                                    "rank's stream (with several frames in flight they include time shared with "
+                                    "other frames' kernels); gather_ms = gather + scatter into the frame on rank 0's stream"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cold"]["rt_main"] = rt_main_cold(scenes)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scenes, name, w, h, nl)
         print(json.dumps(out), flush=True)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 1u
+#define RTX_ABI_VERSION 2u /* 2: rtx_stats grew render_attempts, record_capacity */
 #define RTX_NONE 0xFFFFFFFFu
 
 typedef enum rtx_status {
@@ -183,6 +183,10 @@ typedef struct rtx_stats {
     float kernel_ms[4];     /* trace (with the sorting of the hit records into work
                                lists), shadow+shade kernel, merge, total on the stream
                                (only with RTX_FLAG_TIMING) */
+    uint32_t render_attempts; /* times the frame's kernels ran: 1, or more when the hit
+                               records outgrew their buffer and the frame was rendered
+                               again into a larger one (first frames of a scene only) */
+    uint32_t record_capacity; /* hit records the buffer held on the last attempt */
 } rtx_stats;
 
 /* Library / device ----------------------------------------------------------*/
@@ -219,9 +223,10 @@ uint32_t rtx_part_rows(const rtx_params *p);
  * Replaces the in-memory `Boxs` argument of render_image (raytracing.h:100):
  * validates the description, converts it to the device layout and uploads it
  * to HIP device `device`.  The description is not referenced after return.
- * The first scene created on a device in a process runs rtx_selftest there (about
- * 50 ms) and fails with RTX_ERR_NO_DEVICE if the device's arithmetic does not
- * reproduce the IEEE results the kernels' shortcuts rely on. */
+ * The first scene created on a device in a process runs a sampled version of
+ * rtx_selftest there (one value in 64, under 2 ms) and fails with
+ * RTX_ERR_NO_DEVICE if the device's arithmetic does not reproduce the IEEE
+ * results the kernels' shortcuts rely on; rtx_selftest itself is exhaustive. */
 typedef struct rtx_scene rtx_scene;
 rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, rtx_scene **out);
 void rtx_scene_destroy(rtx_scene *scene);

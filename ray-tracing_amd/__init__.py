@@ -25,6 +25,21 @@ class RtxError(RuntimeError):
 _lib = None
 
 
+def kernel_source_hash():
+    """SHA-256 over the sources librtx_amd.so is built from (csrc/*.h, *.hip, Makefile, in
+    name order).  Measurements kept in files carry it, so that a reader can tell whether they
+    were taken on these kernels."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def lib():
     """Load librtx_amd.so (built in-tree by `make -C ray-tracing_amd/csrc`)."""
     global _lib

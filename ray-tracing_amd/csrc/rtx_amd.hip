@@ -134,42 +134,45 @@ extern "C" int rtx_device_count(void) {
 
 extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
 
-extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) {
+// sampled = false: the exhaustive comparisons (some 50 ms).  sampled = true: one bit pattern
+// pair in 64, a sixteenth of the chain cases and of the division operands (under 2 ms); a
+// part whose v_rcp_f32 / v_rsq_f32 differ from gfx950's would fail either.
+static rtx_status selftest_run(int device, uint64_t out[7], bool sampled) {
     if (!out) return fail(RTX_ERR_INVALID, "null argument");
     if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(device));
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 56));
-    hipError_t e = hipMemset(d, 0, 56);
+    hipError_t e = hipMemsetAsync(d, 0, 56, nullptr);
     if (e == hipSuccess) {
-        selftest_rcp_kernel<<<4096, 256>>>(d + 1, d, d + 6, d + 5);
+        // (one after the other on the null stream; a single synchronisation at the end)
+        selftest_rcp_kernel<<<sampled ? 1024 : 4096, 256>>>(d + 1, d, d + 6, d + 5, sampled ? 64u : 1u);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) {
-            selftest_chain_kernel<<<16384, 256>>>(d + 3, d + 2, d + 4);
+            selftest_chain_kernel<<<sampled ? 1024 : 16384, 256>>>(d + 3, d + 2, d + 4);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e == hipSuccess) {
-            selftest_div_kernel<<<1024, 256>>>(d + 6, d + 5);
+            selftest_div_kernel<<<1024, 256>>>(d + 6, d + 5, sampled ? 256u : 4096u);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpy(h, d, 56, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h, d, 56, hipMemcpyDeviceToHost); // (synchronises)
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
     for (int k = 0; k < 7; k++) out[k] = h[k];
     return RTX_OK;
 }
 
+extern "C" rtx_status rtx_selftest(int device, uint64_t out[7]) { return selftest_run(device, out, false); }
+
 // The kernels' exact arithmetic shortcuts (reciprocal, square root, division, determinant
 // threshold) start from the hardware's v_rcp_f32 / v_rsq_f32 and are exact because of what
 // those return on gfx950, as rtx_selftest establishes value by value.  Hit ids that are
 // silently off on a part that rounds differently would be worse than no result: the first
-// scene created on a device runs the self-test there (some 50 ms) and refuses the device
-// if anything mismatches.
+// scene created on a device runs a sampled self-test there (under 2 ms; rtx_selftest is the
+// exhaustive one) and refuses the device if anything mismatches.
 static std::mutex g_check_mutex;
 static int g_checked[SCRATCH_MAX_DEVICES]; // 0 not yet, 1 passed, 2 failed
 static rtx_status arithmetic_check(int device) {
@@ -177,7 +180,7 @@ static rtx_status arithmetic_check(int device) {
     std::lock_guard<std::mutex> lock(g_check_mutex);
     if (g_checked[device] == 0) {
         uint64_t out[7];
-        if (rtx_status rs = rtx_selftest(device, out); rs != RTX_OK) return rs;
+        if (rtx_status rs = selftest_run(device, out, true); rs != RTX_OK) return rs;
         g_checked[device] = (out[1] == 0 && out[3] == 0 && out[6] == 0) ? 1 : 2;
     }
     if (g_checked[device] == 2)
@@ -551,6 +554,7 @@ static double tile_rects(const rtx_scene *s, const rtx_params *p, DTileRects *ou
 // buffer (queues + one flag byte per tile part).
 struct TilePlan {
     bool queued;
+    double cover; // share of the frame inside the projected top-level boxes, at most
     uint32_t slices, tile_h, tiles, tile_seg;
     uint64_t words;
     DTileRects rects;
@@ -561,6 +565,7 @@ static TilePlan plan_tiles(const rtx_scene *s, const rtx_params *p, uint32_t row
     // tile parts that can hit something are traced, each by the next free wave.  Where
     // nearly every tile has work the fixed assignment is cheaper.
     const double cover = tile_rects(s, p, &t.rects);
+    t.cover = cover;
     t.queued = TRACE_QUEUE && cover < TRACE_QUEUE_MAX_COVER;
     // Lanes per primary ray.  With queues the extra waves walk only the listed tiles.  In a
     // scene with large leaves two lanes share a ray; when the listed tile parts (8 x 4 pixels
@@ -624,9 +629,15 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (hipError_t e = grow(&s->d_first, &s->pix_cap, npix); e != hipSuccess)
             return fail(RTX_ERR_NOMEM, std::string("pixel buffer: ") + hipGetErrorString(e));
         if (s->rec_cap == 0) {
-            // A first guess (96 bytes per record: 50 MB at 3840 x 2160); a frame with more hits
-            // grows the buffers to what it needs and is rendered again.
-            rs = ensure_records(s, std::max<uint64_t>(npix / 16, 1u << 16));
+            // A first guess (96 bytes per record); a frame with more hits grows the buffers to
+            // what it needs and is rendered again.  Only pixels inside the projected top-level
+            // boxes can have records; of the reference's scenes the committed one has the most
+            // per such pixel (1.3; a ray that meets a mesh at all crosses two or three of its
+            // leaf columns), so 2.5 per covered pixel holds a first frame of any of them with
+            // room for the uneven filling of the shards.
+            const uint64_t guess = (uint64_t)(2.5 * plan.cover * (double)npix);
+            rs = ensure_records(s, std::max<uint64_t>(std::min<uint64_t>(guess, std::max<uint64_t>(npix / 2, 1u << 20)),
+                                                      1u << 16));
             if (rs != RTX_OK) return rs;
         }
         if (queued)
@@ -662,7 +673,9 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     const uint32_t merge_blocks = (uint32_t)((npix + MERGE_BLOCK - 1) / MERGE_BLOCK);
 
     uint64_t n_hits = 0;
+    uint32_t attempts = 0;
     for (int attempt = 0; attempt < 3; attempt++) {
+        attempts++;
         HIP_TRY(hipMemsetAsync(wb.ctr, 0, sizeof(DCounters), st));
         if (timing) HIP_TRY(hipEventRecord(s->ev[0], st));
 #define LAUNCH_TRACE(SL)                                                                                     \
@@ -787,6 +800,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         stats->shadow_tests = ((uint64_t)s->h_ctr->leaf_prims + s->h_ctr->bounce_prims) * p->n_lights;
         stats->lit_samples = s->h_ctr->lit;
         stats->shadow_tests_run = s->h_ctr->tests_run;
+        stats->render_attempts = attempts;
+        stats->record_capacity = wb.rec_cap;
         if (timing) {
             for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
             HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[3], s->ev[0], s->ev[3]));

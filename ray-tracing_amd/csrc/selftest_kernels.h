@@ -6,13 +6,18 @@
 // rcp2_exact against the plain division and sqrt2_exact against sqrtf, for every binary32
 // value in their ranges; the threshold on the reciprocal that stands for intersect.h:39's
 // test of the determinant, for every binary32 value.
+// every = 1 checks all 2^32 bit patterns; every = n checks one pair of neighbouring patterns in
+// n (evenly spaced, so every exponent and sign is visited): the sampled check that scene
+// creation runs.
 __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long *checked,
-                                    unsigned long long *bad_sqrt, unsigned long long *checked_sqrt) {
+                                    unsigned long long *bad_sqrt, unsigned long long *checked_sqrt, uint32_t every) {
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t nb = 0, nc = 0, sb = 0, sc = 0;
     // 2^32 bit patterns, two per iteration
-    for (unsigned long long i = (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x) * 2; i < (1ull << 32);
-         i += (unsigned long long)stride * 2) {
+    const unsigned long long pairs = (1ull << 31) / every;
+    for (unsigned long long pr = blockIdx.x * blockDim.x + threadIdx.x; pr < pairs; pr += stride) {
+        // (the sampled pairs also move through the low mantissa bits)
+        const unsigned long long i = (pr * every + (pr * 0x9E3779B1ull >> 7) % every) * 2;
         const float x = __uint_as_float((uint32_t)i), y = __uint_as_float((uint32_t)i + 1u);
         const v2f r = rcp2_exact((v2f){x, y});
         const bool inx = __builtin_fabsf(x) >= RCP2_MIN && __builtin_fabsf(x) < RCP2_MAX;
@@ -55,10 +60,10 @@ __global__ void selftest_rcp_kernel(unsigned long long *bad, unsigned long long 
 // div2_exact / normalize2 against the plain quotient: pseudo-random denominators over
 // DIV2_DEN_MIN..DIV2_DEN_MAX (log-uniform) and numerators from DIV2_NUM_MIN up to 4 d,
 // of both signs, plus vectors through normalize2 against f3_normalize.
-__global__ void selftest_div_kernel(unsigned long long *bad, unsigned long long *checked) {
+__global__ void selftest_div_kernel(unsigned long long *bad, unsigned long long *checked, uint32_t iterations) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nb = 0, nc = 0;
-    for (uint32_t it = 0; it < 4096; it++) {
+    for (uint32_t it = 0; it < iterations; it++) {
         uint32_t u[6];
         for (int k = 0; k < 3; k++) light_sample_u(0x51ED270Bu + k, tid, it & 0xFFFFu, it >> 16, u[2 * k], u[2 * k + 1]);
         uint32_t w[4];

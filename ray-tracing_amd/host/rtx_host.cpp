@@ -7,6 +7,7 @@
 // boxes come out bit-identical; build without -ffast-math and with -ffp-contract=off.
 #include "../../include/rtx_dropin.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -545,6 +546,8 @@ bool render_to_memory(const Light &light, const Boxs &boxs, std::vector<uint8_t>
             stats->shadow_tests += part_stats[k].shadow_tests;
             stats->lit_samples += part_stats[k].lit_samples;
             stats->shadow_tests_run += part_stats[k].shadow_tests_run;
+            stats->render_attempts = std::max(stats->render_attempts, part_stats[k].render_attempts);
+            stats->record_capacity += part_stats[k].record_capacity;
         }
     }
     return true;
@@ -660,9 +663,13 @@ bool render_image(Light &light, Boxs &boxs) {
         std::fprintf(stderr, "render_image: %s\n", error.c_str());
         return false;
     }
-    // raytracing.h:132-135 prints "Rendering image... N %" after every tenth row; here the
-    // rows arrive all at once
-    if (!cfg.quiet) std::printf("Rendering image... 100 %%\r");
+    // raytracing.h:132-135 prints "Rendering image... N %" after every tenth row, N = rows
+    // done / 10, i.e. the percentage of its 1000-row frame.  Here the rows arrive all at once:
+    // the same lines, one per tenth row, N the percentage of this frame's rows.
+    if (!cfg.quiet)
+        for (uint32_t j = 0; j < cfg.frame.height; j++)
+            if ((j + 1) % 10 == 0)
+                std::printf("Rendering image... %u %%\r", (unsigned)(((uint64_t)(j + 1) * 100) / cfg.frame.height));
     const std::string &path = cfg.output;
     const bool ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
     const bool saved = ppm ? rtx_host::write_ppm(path, rgb.data(), cfg.frame.width, cfg.frame.height)

@@ -26,7 +26,7 @@ def test_header_functions_are_exported(rtx):
 def test_struct_sizes_match_the_header(capi):
     assert C.sizeof(capi.Material) == 32 and C.sizeof(capi.Light) == 24
     assert C.sizeof(capi.Prim) == 48 and C.sizeof(capi.Node) == 32 and C.sizeof(capi.Leaf) == 8
-    assert C.sizeof(capi.Hit) == 32 and C.sizeof(capi.Params) == 52 and C.sizeof(capi.Stats) == 64
+    assert C.sizeof(capi.Hit) == 32 and C.sizeof(capi.Params) == 52 and C.sizeof(capi.Stats) == 72
 
 
 def test_defaults_are_the_reference_settings(rtx, capi):
@@ -36,7 +36,7 @@ def test_defaults_are_the_reference_settings(rtx, capi):
     assert bytes(p) == bytes(q)
     assert (p.width, p.height, p.n_lights, p.max_depth) == (1000, 1000, 1, 0)  # raytracing.h:12-19
     assert abs(p.acne - 0.01) < 1e-9 and list(p.camera) == [500.0, 500.0, 3000.0]
-    assert rtx.lib().rtx_abi_version() == 1
+    assert rtx.lib().rtx_abi_version() == 2
 
 
 def test_part_rows(rtx, capi):

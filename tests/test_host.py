@@ -182,7 +182,7 @@ def test_rt_main_renders_and_reports(scenes, tmp_path):
                          capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr
     want = (r"RAY TRACING by Romain Roy\n-------------------------\nStart time: \d+:\d+:\d+\n"
-            r"Rendering image\.\.\. 0 %\rRendering image\.\.\. 100 %\r\nImage successfully saved!\n"
+            r"Rendering image\.\.\. 0 %\r(Rendering image\.\.\. \d+ %\r){19}Rendering image\.\.\. 100 %\r\nImage successfully saved!\n"
             r"Finish time: \d+:\d+:\d+\nCompute time: 0:0:\d+\n"
             r"Compute time \(ms\): [0-9.]+ \(320 x 200, 3 light samples, 1 GPU\(s\)\)\n$")
     assert re.match(want, out.stdout.decode()), out.stdout

@@ -5,7 +5,8 @@
 
 Every case draws a scene, a box depth, a light height, an acne offset, a sample count
 and a sampler seed, renders a small frame on both sides and requires: the same hit
-records (ids, distance bits), the same number of lit samples (every occlusion decision),
+records (ids, distance bits), the same number of lit samples (every occlusion decision) as
+the oracle and as the GPU's own run with RTX_FLAG_NO_SCREEN (every leaf primitive tested),
 RGB within 1/255 on >= 99.9 % of the pixels, per-record colours within 5e-3 of
 |channel| + 0.01 + a thousandth of the record's largest channel.  Where the GPU adds the
 samples of a record in index order (fewer than 129 samples,
@@ -104,7 +105,15 @@ for case in range(n_cases):
     sc = rtx.Scene(d)
     rgb_g, hits_g = sc.render_hits(p)
     _, st_g = sc.render(p)
+    # the same frame with every leaf primitive tested for every shadow ray (the reference's loop
+    # nest on the GPU): the candidate screens must not change one occlusion decision
+    r = capi.Params.from_buffer_copy(p)
+    r.flags |= capi.RTX_FLAG_NO_SCREEN
+    _, st_u = sc.render(r)
     sc.close()
+    ok_screen = st_u.lit_samples == st_g.lit_samples and st_u.shadow_tests == st_g.shadow_tests
+    if max_depth == 0:
+        ok_screen = ok_screen and st_u.shadow_tests_run == st_u.shadow_tests
     ok_ids = len(hits_g) == len(hits_c) and all(np.array_equal(hits_g[k], hits_c[k]) for k in ("pixel", "ordinal", "leaf", "prim"))
     ok_t = ok_ids and np.array_equal(hits_g["t"].view(np.uint32), hits_c["t"].view(np.uint32))
     ok_lit = st_g.lit_samples == st_c.shaded_samples
@@ -116,12 +125,12 @@ for case in range(n_cases):
         # noise of the record's large channels: measure it against those as well
         rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
         rel = float((np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-2 + 1e-3 * rec_max)).max())
-    ok = ok_ids and ok_t and ok_lit and within >= 0.999 and rel < (5e-4 if in_order else 5e-3)
+    ok = ok_ids and ok_t and ok_lit and ok_screen and within >= 0.999 and rel < (5e-4 if in_order else 5e-3)
     bad += not ok
-    print("%s case %2d corner %d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s "
+    print("%s case %2d corner %d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s screens %s "
           "(%d vs %d) part %d/%d cam %s rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
           ("ok " if ok else "BAD", case, corner, name, depth, light_z, acne, nl, w, h, flags, max_depth, len(hits_c), ok_ids, ok_t,
-           ok_lit, st_g.lit_samples, st_c.shaded_samples, part, n_parts, camera, within, float((diff == 0).mean()), rel,
+           ok_lit, ok_screen, st_g.lit_samples, st_c.shaded_samples, part, n_parts, camera, within, float((diff == 0).mean()), rel,
            100.0 * st_g.shadow_tests_run / max(st_g.shadow_tests, 1), t_cpu), flush=True)
 print("%d cases, %d bad, %.0f s" % (n_cases, bad, time.time() - t_start))
 sys.exit(1 if bad else 0)

@@ -5,9 +5,13 @@
 
 Per workload: the last dispatch of the shading kernel in pmc_fetch_<w>.txt and
 pmc_write_<w>.txt (summaries by tools/pmc_summary.py; counters in KB)."""
+import importlib
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 N_SIMDS = 1024  # 256 CUs x 4
@@ -27,12 +31,14 @@ def last_shade(path, counter):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     out = {"note": "HBM bytes per launch of the shading kernel = (FETCH_SIZE + WRITE_SIZE) * 1024, raw rocprofv3 "
-                   "counters from separate --pmc runs (profiles/r2_pmc_hbm_<workload>.txt).  On gfx950 FETCH_SIZE "
+                   "counters from separate --pmc runs (profiles/r<round>_pmc_hbm_<workload>.txt).  On gfx950 FETCH_SIZE "
                    "reports half the bytes of wide coalesced streaming reads; this kernel reads through scalar "
                    "loads and dword scratch reloads (uncalibrated widths), so the true figure lies between "
                    "shade_kernel[w] and shade_kernel_upper[w] = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
            "shade_kernel": {}, "shade_kernel_upper": {}, "fetch_kb": {}, "write_kb": {}}
-    for w in ("buddha", "bunny", "dino_spheres", "multi", "default"):
+    # the kernels these counters were taken on: bench.py quotes them only for the same sources
+    out["kernel_source_sha256"] = importlib.import_module("ray-tracing_amd").kernel_source_hash()
+    for w in ("buddha", "bunny", "dino_spheres", "multi", "default", "default_500"):
         try:
             f = last_shade("%s/pmc_fetch_%s.txt" % (src, w), "FETCH_SIZE")
             wr = last_shade("%s/pmc_write_%s.txt" % (src, w), "WRITE_SIZE")
