@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,21 @@ extern "C" int rtx_device_count(void) {
 
 extern "C" const char *rtx_last_error(void) { return g_err.c_str(); }
 
+// RTX_TRACE_COLD=1 in the environment: where the time of the first calls goes, on stderr.
+struct ColdTrace {
+    bool on = getenv("RTX_TRACE_COLD") != nullptr;
+    double t = now();
+    static double now() {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    void mark(const char *where, const char *what) {
+        if (!on) return;
+        const double n = now();
+        fprintf(stderr, "%s: %-52s %8.3f ms\n", where, what, n - t);
+        t = n;
+    }
+};
+
 // sampled = false: the exhaustive comparisons (some 50 ms).  sampled = true: one bit pattern
 // pair in 64, a sixteenth of the chain cases and of the division operands (under 2 ms); a
 // part whose v_rcp_f32 / v_rsq_f32 differ from gfx950's would fail either.
@@ -141,13 +157,17 @@ static rtx_status selftest_run(int device, uint64_t out[7], bool sampled) {
     if (!out) return fail(RTX_ERR_INVALID, "null argument");
     if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(device));
+    ColdTrace tr;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 56));
+    tr.mark("selftest", "hipMalloc");
     hipError_t e = hipMemsetAsync(d, 0, 56, nullptr);
+    tr.mark("selftest", "hipMemsetAsync");
     if (e == hipSuccess) {
         // (one after the other on the null stream; a single synchronisation at the end)
         selftest_rcp_kernel<<<sampled ? 1024 : 4096, 256>>>(d + 1, d, d + 6, d + 5, sampled ? 64u : 1u);
         e = hipGetLastError();
+        tr.mark("selftest", "first kernel launch");
         if (e == hipSuccess) {
             selftest_chain_kernel<<<sampled ? 1024 : 16384, 256>>>(d + 3, d + 2, d + 4);
             e = hipGetLastError();
@@ -158,7 +178,9 @@ static rtx_status selftest_run(int device, uint64_t out[7], bool sampled) {
         }
     }
     unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
+    tr.mark("selftest", "other launches");
     if (e == hipSuccess) e = hipMemcpy(h, d, 56, hipMemcpyDeviceToHost); // (synchronises)
+    tr.mark("selftest", "kernels run, counters copied back");
     (void)hipFree(d);
     if (e != hipSuccess) return fail(RTX_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
     for (int k = 0; k < 7; k++) out[k] = h[k];
@@ -391,13 +413,18 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     int ndev = rtx_device_count();
     if (ndev <= 0) return fail(RTX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(RTX_ERR_INVALID, "device index out of range");
+    ColdTrace tr;
+    auto mark = [&](const char *what) { tr.mark("rtx_scene_create", what); };
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTX_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+    mark("device selected, properties read");
     if (rtx_status rs = scratch_resolve(device); rs != RTX_OK) return rs;
+    mark("static work area located (loads the code object)");
     if (rtx_status rs = arithmetic_check(device); rs != RTX_OK) return rs;
+    mark("arithmetic self-test (sampled, first scene only)");
 
     rtx_scene *s = new rtx_scene();
     s->device = device;
@@ -433,6 +460,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
         return fail(e == hipErrorOutOfMemory ? RTX_ERR_NOMEM : RTX_ERR_HIP,
                     std::string("scene upload: ") + hipGetErrorString(e));
     }
+    mark("scene arrays, counters, events allocated and uploaded");
     *out = s;
     return RTX_OK;
 }
