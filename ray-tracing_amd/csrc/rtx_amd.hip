@@ -376,6 +376,14 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
             const double l1 = sqrt((double)e1x * e1x + (double)e1y * e1y + (double)e1z * e1z);
             const double l2 = sqrt((double)e2x * e2x + (double)e2y * e2y + (double)e2z * e2z);
             if (!(l1 * l2 < DET_BOUND)) wide_dets = 1;
+            {
+                const double nx = (double)e1y * e2z - (double)e1z * e2y, ny = (double)e1z * e2x - (double)e1x * e2z,
+                             nz = (double)e1x * e2y - (double)e1y * e2x;
+                const double area2 = sqrt(nx * nx + ny * ny + nz * nz);
+                const double shape = (area2 > 0.0) ? l1 * l2 / area2 * 1.0001 : INFINITY;
+                o.shape = (shape < 3.0e38) ? (float)shape : INFINITY;
+                o.ell = (float)std::min((l1 + l2) * 1.0001, 3.0e38);
+            }
             for (int c = 0; c < 9; c++) coord_max = std::max(coord_max, (double)fabsf(p.g[c]));
         } else {
             o.a = host_f3(p.g);
@@ -818,6 +826,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
                 c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
         fprintf(stderr, "classes (sorted heavy, sorted light, plain heavy, plain light): %u %u %u %u; sorted records that sort %llu; plain records not closed %llu\n",
                 s->h_ctr->cls[0].count, s->h_ctr->cls[1].count, s->h_ctr->cls[2].count, s->h_ctr->cls[3].count, c[8], c[9]);
+        fprintf(stderr, "grazing guard: pairs listed %llu in %llu records, records shaded without screens %llu, primitives screened %llu\n",
+                c[10], c[11], c[12], c[13]);
     }
 #endif
     s->n_hits = n_hits;

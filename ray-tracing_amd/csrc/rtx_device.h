@@ -52,7 +52,9 @@ struct __attribute__((aligned(64))) DPrim {
     f3 a, b, c, n;
     uint32_t type_mat; // type | material << 8
     uint32_t id;
-    uint32_t pad[2];
+    // triangle: |e1| |e2| / |e1 x e2| and |e1| + |e2|, rounded up (the shading kernel's screens
+    // bound the rounding of the intersection test with them); infinite for a triangle without area
+    float shape, ell;
 };
 
 // Material with the ray-independent subexpressions of shade.h folded in.
@@ -127,7 +129,7 @@ struct DCounters {
     unsigned long long tests_run;  // shadow-ray primitive tests executed
     unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
     unsigned long long bounce_prims; // sum of the leaf sizes over those
-    uint32_t pad1[20];
+    uint32_t pad1[52]; // (the measurement builds keep their statistics here)
     // Hit records appended per shard of the record array (may exceed the shard's capacity).
     // The trace kernel appends with one returning atomic per wave and leaf; on one word
     // those would complete at ~50 M/s chip-wide and pace the kernel, so the array is cut

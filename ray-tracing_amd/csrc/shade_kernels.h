@@ -161,7 +161,7 @@ void shade_kernel(
         for (int k = 0; k < 8; k++) atomicAdd(out + k, tot.st[k]);
         if (atomicMax(out + 8, tot.st[8]) < tot.st[8]) out[9] = tot.st[9]; // (the longest record; racy, good enough)
 #else
-        for (int k = 0; k < 10; k++) atomicAdd(out + k, tot.st[k]);
+        for (int k = 0; k < 14; k++) atomicAdd(out + k, tot.st[k]);
 #endif
     }
 #endif

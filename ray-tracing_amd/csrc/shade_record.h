@@ -39,19 +39,10 @@
 //  * the screens' own plane arithmetic and the rounding of the normalised ray direction:
 //    each at most 2^-20 times the largest coordinate in play; screen_margin() raises the
 //    margin with the scene's size so that this stays below a quarter of it;
-//  * the float test itself (intersect.h:28-67).  It can accept a ray that misses only if its
-//    computed barycentric coordinates land in the triangle although the exact ones do not.
-//    With eps = 2^-24, s = o - v0, ell = |e1| + |e2|, shape = |e1| |e2| / |e1 x e2| and
-//    nd = |n . d| (cosine between ray and triangle normal), adding up the rounding of the
-//    test's operations bounds the distance between the exact and the computed crossing
-//    point of the triangle's plane by  r <= 16 eps shape (|s| + ell) / nd + 2.1 eps ell.
-//    A wrongly accepted ray crosses the plane within r of the triangle, so a triangle that is
-//    outside the pyramid by m can only be wrongly accepted by rays with
-//    nd <= 16 eps shape (|s| + ell) / m  (about 1.5e-4, i.e. within 0.01 degrees of the
-//    triangle's own plane, at 10 units from a well-shaped triangle with m = 0.1), and then
-//    only if the rounding errors happen to add up towards the triangle.  Those rays are not
-//    covered by a proof; RTX_FLAG_NO_SCREEN runs the reference's full loop nest, and the
-//    tests require equal lit-sample counts with and without the screens.
+//  * the float test itself (intersect.h:28-67), which can accept a ray that misses the triangle
+//    in exact arithmetic when ray and start point lie almost in the triangle's plane: the
+//    grazing guard below bounds when, and hands those (triangle, sample) pairs to the float
+//    test itself, so that no pair is dropped that the reference's test would accept.
 #define CAND_MAX 512
 // Margin of the candidate screens, in world units (raised for scenes with very large
 // coordinates, see screen_margin).
@@ -164,48 +155,208 @@ __device__ __forceinline__ void setup_planes(ShadeLds &L, uint32_t lane, f3 o_fi
     }
 }
 
-// True if triangle (v0, v0 + e1, v0 + e2) lies outside the pyramid of the record's shadow
-// rays by the margin.
-__device__ __forceinline__ bool outside_pyramid(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi,
-                                                float margin) {
+// Distance by which triangle (v0, v0 + e1, v0 + e2) lies outside the pyramid of the record's
+// shadow rays: the largest, over the faces, of the smallest distance of a vertex beyond the
+// face as seen from the first and from the last start point (zero or negative: not outside
+// that face).  z_lo / z_hi: the lowest start point when the light is above all of them (every
+// ray then moves up), the highest when it is below, else -/+ 3e38.  Finite coordinates only.
+__device__ __forceinline__ float pyramid_separation(const ShadeLds &L, f3 v0, f3 e1, f3 e2, float z_lo, float z_hi) {
     const f3 v1 = f3_add(v0, e1), v2 = f3_add(v0, e2);
-    const float lim = -margin;
-    bool out = false;
+    float sep = fmaxf(z_lo - fmaxf(fmaxf(v0.z, v1.z), v2.z), fminf(fminf(v0.z, v1.z), v2.z) - z_hi);
 #pragma unroll 1
     for (int e = 0; e < 4; e++) {
-        // outside face e as seen from the first AND from the last start point
-        bool both = true;
+        float worst = -3.0e38f; // the vertex nearest to (or farthest inside) face e, from either end
 #pragma unroll
         for (int w = 0; w < 2; w++) {
             const float4 pl = L.plane[e + 4 * w];
             const float d0 = pl.x * v0.x + pl.y * v0.y + pl.z * v0.z - pl.w;
             const float d1 = pl.x * v1.x + pl.y * v1.y + pl.z * v1.z - pl.w;
             const float d2 = pl.x * v2.x + pl.y * v2.y + pl.z * v2.z - pl.w;
-            both &= (d0 < lim) & (d1 < lim) & (d2 < lim);
+            worst = fmaxf(worst, fmaxf(fmaxf(d0, d1), d2));
         }
-        out |= both;
+        sep = fmaxf(sep, -worst);
     }
-    // all rays move towards the light plane in z
-    out |= (v0.z < z_lo) & (v1.z < z_lo) & (v2.z < z_lo);
-    out |= (v0.z > z_hi) & (v1.z > z_hi) & (v2.z > z_hi);
-    return out;
+    return sep;
+}
+
+// ---- grazing guard ------------------------------------------------------------------
+// A screen drops a (triangle, sample) pair when a plane through the sample's start point o
+// has the ray on one side and the whole triangle at least m beyond it on the other: in
+// exact arithmetic the ray misses.  The reference's float test (intersect.h:28-67) can
+// still accept such a ray, and then the reference counts the sample as occluded.  What
+// follows shows when it cannot, and graze_check() / graze_resolve() deal with the rest.
+//
+// The float test, on its inputs d, e1, e2, s' = fl(o - v0), computes rounded versions of
+//   A = e1 . (d x e2),  U = s' . (d x e2),  V = d . (s' x e1),  T = e2 . (s' x e1),
+// which satisfy A s' = U e1 + V e2 - T d exactly (Cramer's rule).  With eps = 2^-24,
+// a = |e1|, b = |e2|, sigma = |s'| and |d| = 1 up to 3 eps, the roundings of the products,
+// differences and left-to-right sums give (first order; the code's constant GRAZE_EPS has
+// room for the rest)
+//   |dA| <= 6.5 eps a b,  |dU| <= 6.5 eps sigma b,  |dV| <= 6.5 eps sigma a,
+//   |dT| <= 6.5 eps sigma a b        (6.5 > 3 + 2 sqrt 3: a three-term dot product of a
+//                                     cross product whose components carry 2 eps each).
+// Acceptance (say with A~ > 0; the other sign is symmetric) needs U~ >= 0, V~ >= 0,
+// U~ + V~ <= A~ (1 + 3 eps) and T~ > 0.  Let w be the unit normal of the separating plane
+// and g_i = w . (v_i - o') <= -m for the three vertices.  Dotting the identity with w:
+//   T (w . d) = (A - U - V) g_0 + U g_1 + V g_2 .
+// With the rounded coefficients the right side is at most -m A~ + 3 eps A~ sigma; replacing
+// them by the exact ones changes it by at most |dA| sigma + |dU| a + |dV| b; the left side is
+// at least -(|dT| + 3 eps sigma a b) since T > -|dT| and w . d >= -3 eps.  Hence
+//   A~ <= 29 eps sigma a b / (m - 3 eps sigma) =: A_max :
+// only a ray within about 1e-4 of parallel to the triangle's plane can be wrongly accepted.
+// For such a ray U~, V~ <= A~ (1 + 2 eps) as well, and the identity dotted with d bounds
+//   |T| <= A_max (sigma + a + b) + 19.4 eps sigma a b ,
+// i.e. the start point lies within |T| / |e1 x e2| of the triangle's plane: with
+// shape = a b / |e1 x e2| and ell = a + b,
+//   rho = eps sigma (shape (29 (sigma + ell) / m + 19.4) + 8)
+// (the 8 eps sigma cover the guard's own evaluation of the distance).  A pair whose start
+// point is farther than rho from the triangle's plane is rejected by the float test.
+//
+// The start points of a record lie on a segment, so their distances from a triangle's plane
+// form an arithmetic sequence: at most a few consecutive samples can be within rho (rho is
+// below a sample's step in the usual case).  graze_check() finds them for every triangle a
+// screen is about to drop: none - dropping is safe; more than GRAZE_KMAX, or anything that
+// cannot be bounded (a triangle without area, start points off the segment because the acne
+// chain has no closed form, coordinates so large that m is within rounding) - the triangle
+// is kept for every sample; else the (triangle, sample) pairs go to a list, and
+// graze_resolve() looks at each pair's ray: if it is within A_max of parallel to the triangle's
+// plane as well, the record is shaded without screens.  m is half the frame's screen margin: a quarter of that margin
+// is the screens' own rounding (screen_margin()), and the rest covers s' against o - v0.
+#define GRAZE_EPS 6.1e-8f // 2^-24 and room for the higher-order terms
+#define GRAZE_KMAX 2u
+#define GRAZE_LIST 256u   // pairs per record; a record with more is shaded without screens
+
+struct GrazeCtx {
+    f3 o1, on;    // first and last start point of the level
+    float steps;  // n_lights - 1
+    float m4;     // screen margin / 4
+    float drift;  // bound on a start point's distance from the segment (0 with the closed form)
+    bool closed;
+};
+__device__ __forceinline__ GrazeCtx graze_ctx(bool closed, f3 o_first, f3 o_last, uint32_t n_lights, float base_margin,
+                                              float margin) {
+    GrazeCtx g;
+    g.o1 = o_first;
+    g.on = o_last;
+    g.steps = (float)(n_lights > 0 ? n_lights - 1u : 0u);
+    g.m4 = 0.25f * base_margin;
+    g.drift = closed ? 0.f : margin - base_margin; // what screen_segment added for the chain's rounding
+    g.closed = closed;
+    return g;
+}
+
+// For the triangle p that a screen is about to drop for some or all samples of the record,
+// being outside the separating planes by `sep` (at least the record's screen margin):
+// 0 = safe, 2 = keep it for every sample, 1 = safe but for samples first .. first + count - 1
+// (count <= GRAZE_KMAX; sample k0 starts at the (k0 + 1)-th point of the segment).
+__device__ __forceinline__ uint32_t graze_check(const GrazeCtx &g, const DPrim *__restrict__ p, float sep,
+                                                uint32_t &first, uint32_t &count) {
+    const f3 s1 = f3_sub(g.o1, p->a), sn = f3_sub(g.on, p->a);
+    const float sig = __builtin_sqrtf(fmaxf(f3_dot(s1, s1), f3_dot(sn, sn))) * 1.001f;
+    if (!(GRAZE_EPS * 5.f * sig <= g.m4)) return 2u; // (a NaN ends here too)
+    // m: the separation less the start points' distance from the segment, the screens' own
+    // rounding (a quarter of the margin) and s' against o - v0 (the check above: another quarter)
+    const float m = sep - g.drift - 2.f * g.m4;
+    if (!(m >= 2.f * g.m4)) return 2u;
+    const float rho = GRAZE_EPS * sig * (p->shape * (29.f * (sig + p->ell) / m + 19.4f) + 8.f) * 1.05f + g.drift + 1.0e-30f;
+    const float h1 = f3_dot(p->n, s1), hn = f3_dot(p->n, sn);
+    if ((h1 > rho && hn > rho) || (h1 < -rho && hn < -rho)) return 0u;
+    if (!g.closed) return 2u;
+    // distance of start point k0 from the plane: h1 + k0 * dh, k0 = 0 .. steps
+    const float dh = (g.steps > 0.f) ? (hn - h1) / g.steps : 0.f;
+    float lo = 0.f, hi = g.steps;
+    if (dh != 0.f) {
+        const float x = (-rho - h1) / dh, y = (rho - h1) / dh;
+        lo = fmaxf(__builtin_ceilf(fminf(x, y) - 0.01f), 0.f);
+        hi = fminf(__builtin_floorf(fmaxf(x, y) + 0.01f), g.steps);
+    } else if (!(__builtin_fabsf(h1) <= rho)) {
+        return (h1 == h1) ? 0u : 2u;
+    }
+    const float n = hi - lo + 1.f;
+    if (n <= 0.f) return 0u;
+    if (!(n <= (float)GRAZE_KMAX)) return 2u; // (rho infinite or NaN: a triangle without area)
+    first = (uint32_t)lo;
+    count = (uint32_t)n;
+    return 1u;
+}
+
+// Appends the pairs of the lanes with code == 1 to the record's list (entry: primitive offset
+// in the leaf | sample << 16).  All lanes of the wave take part.
+__device__ __forceinline__ void graze_push(uint32_t *__restrict__ list, uint32_t &n_list, uint32_t code,
+                                           uint32_t prim, uint32_t first, uint32_t count) {
+#pragma unroll
+    for (uint32_t r = 0; r < GRAZE_KMAX; r++) {
+        const bool push = code == 1u && r < count;
+        const unsigned long long mask = __ballot(push);
+        if (mask == 0) continue;
+        if (push) {
+            const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (pos < GRAZE_LIST) list[pos] = prim | ((first + r) << 16);
+        }
+        n_list += (uint32_t)__popcll(mask);
+    }
+}
+
+// The listed pairs, one per lane: the sample's ray can only be accepted by the float test if
+// it is within A_max of parallel to the triangle's plane (first part of the argument above:
+// acceptance needs |A~| <= A_max = 29 eps sigma a b / m; here with a b <= (ell / 2)^2, m at its
+// smallest, half the screen margin, and 7 eps a b more for A~ against the value computed
+// here).  Tested on the direction before it is normalised, D = light - start point:
+// |e1 . (D x e2)| > A_max |D| clears the pair.  True if a pair is not cleared, or the list
+// overflowed: the record is then shaded without screens (a few records in a thousand).
+__device__ __forceinline__ bool graze_resolve(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
+                                              const uint32_t *__restrict__ list, uint32_t n_list, f3 p0, f3 dlt,
+                                              uint32_t pixel, uint32_t leaf, uint32_t k_off, uint32_t lane) {
+    if (n_list > GRAZE_LIST) return true;
+    const float per_m = 2.f / (0.5f * fr.cull_margin); // (half the margin, and half of that again as in graze_check)
+    for (uint32_t base = 0; base < n_list; base += 64) {
+        bool open = false;
+        if (base + lane < n_list) {
+            const uint32_t w = list[base + lane], k0 = w >> 16;
+            const DPrim *__restrict__ p = leaf_prims + (w & 0xFFFFu);
+            const float s = (float)(k0 + 1u);
+            const f3 o = f3_make(p0.x + s * dlt.x, p0.y + s * dlt.y, p0.z + s * dlt.z);
+            f3 l = fr.light_pos;
+            light_sample(fr.seed, pixel, leaf, k_off + k0, l.x, l.y);
+            const f3 D = f3_sub(l, o), sv = f3_sub(o, p->a);
+            const float A = f3_dot(p->b, f3_cross(D, p->c));
+            const float sig = __builtin_sqrtf(f3_dot(sv, sv)) * 1.001f, ab = 0.25f * p->ell * p->ell;
+            const float a_max = GRAZE_EPS * ab * (29.f * sig * per_m + 7.f) * 1.05f;
+            // cleared when A^2 > a_max^2 |D|^2 (a NaN leaves the pair open)
+            open = !(A * A > a_max * a_max * f3_dot(D, D) * 1.001f);
+        }
+        if (__any(open)) return true;
+    }
+    return false;
 }
 
 // Screens primitives [seg, seg + n) of the leaf (n <= CAND_MAX) and writes the
-// survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.
+// survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.  G (may be
+// null: nothing is dropped then) is the record's grazing guard: the pairs it cannot clear go
+// to graze_list / n_graze.
 __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
                                                       uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
-                                                      float z_hi, float margin) {
+                                                      float z_hi, float margin, const GrazeCtx *G,
+                                                      uint32_t *__restrict__ graze_list, uint32_t &n_graze) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
         bool keep = false;
+        uint32_t code = 0, first = 0, cnt = 0;
         if (t < n) {
             const DPrim *p = leaf_prims + seg + t;
             keep = true;
-            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE)
-                keep = !outside_pyramid(L, p->a, p->b, p->c, z_lo, z_hi, margin);
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                const float sep = pyramid_separation(L, p->a, p->b, p->c, z_lo, z_hi);
+                keep = !(sep > margin);
+                if (!keep && G) {
+                    code = graze_check(*G, p, sep, first, cnt);
+                    keep = code == 2u;
+                }
+            }
         }
+        if (G) graze_push(graze_list, n_graze, code, seg + t, first, cnt);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -244,7 +395,7 @@ struct ShadeTotals {
     uint32_t lit = 0, bounce_hits = 0;
     unsigned long long tests = 0, bounce_prims = 0;
 #if defined(STEP_STATS) || defined(PHASE_TIMES)
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 };
 // (measurement build only, -DPHASE_TIMES) wave cycles per phase of shade_record_sorted
@@ -355,8 +506,8 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const float margin = screen_segment(closed, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
         const float zl = fr.light_pos.z;
         const float o_zmin = fminf(o_first.z, o_last.z), o_zmax = fmaxf(o_first.z, o_last.z);
-        const float z_lo = (zl > o_zmax) ? o_zmin - margin : -3.0e38f;
-        const float z_hi = (zl < o_zmin) ? o_zmax + margin : 3.0e38f;
+        const float z_lo = (zl > o_zmax) ? o_zmin : -3.0e38f; // all rays move towards the light plane in z
+        const float z_hi = (zl < o_zmin) ? o_zmax : 3.0e38f;
 #ifdef DUP_SETUP
         { // (measurement build only) the per-record set-up a second time, on other values
             f3 o2, d2;
@@ -447,15 +598,30 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
-#ifdef DUP_SCREEN
-                    n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
-                                              z_lo, z_hi, margin * 1.5f);
-                    asm volatile("" ::"s"(n_cand));
+                    const uint32_t seg_n = min(count - seg, (uint32_t)CAND_MAX);
+                    // (a margin no triangle can exceed screens nothing: no guard needed)
+                    const bool screened = margin < 1.0e38f;
+                    const GrazeCtx G = graze_ctx(closed, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
+                    uint32_t *graze_list = reinterpret_cast<uint32_t *>(L.chain); // (the chain is unused with the closed form,
+                                                                                  //  and only then are pairs listed)
+                    uint32_t n_graze = 0;
+                    n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, margin, screened ? &G : nullptr,
+                                              graze_list, n_graze);
                     wave_lds_sync();
+#ifdef STEP_STATS
+                    tot.st[10] += n_graze;      // pairs listed
+                    tot.st[11] += n_graze != 0; // records with a list
+                    tot.st[13] += seg_n;        // primitives screened
 #endif
-                    n_cand = build_candidates(L, leaf_prims, seg, min(count - seg, (uint32_t)CAND_MAX), lane,
-                                              z_lo, z_hi, margin);
-                    wave_lds_sync();
+                    if (n_graze && graze_resolve(fr, leaf_prims, graze_list, n_graze, p0, dlt, pixel, leaf, k_off, lane)) {
+#ifdef STEP_STATS
+                        tot.st[12]++; // records shaded without screens
+#endif
+                        wave_lds_sync();
+                        n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, 3.0e38f, nullptr, graze_list,
+                                                  n_graze);
+                        wave_lds_sync();
+                    }
                     PHASE_MARK(1);
                 }
                 if (n_cand == 0) continue;

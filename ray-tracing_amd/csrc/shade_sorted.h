@@ -63,16 +63,19 @@ struct RayFan {
     float h[2];                 // |z_light - o.z|
     float gx0[2], gy0[2];       // 250 - o.x, 250 - o.y
     float thr[2];               // margin times (an upper bound of) the norm of a plane's normal
+    float per_thr[2];           // margin / thr: turns a plane function's value into a distance (at least)
     float sigma;                // +1 light above both start points, -1 below, 0 neither
-    float z_lo, z_hi;           // all rays stay within z_lo <= z (or z <= z_hi)
+    float z_lo, z_hi;           // all rays stay within z_lo <= z (or z <= z_hi), before the margin
+    float margin;
 };
 
 __device__ __forceinline__ RayFan make_fan(f3 o_first, f3 o_last, float zl, float margin) {
     RayFan f;
     const float o_zmin = fminf(o_first.z, o_last.z), o_zmax = fmaxf(o_first.z, o_last.z);
     f.sigma = (zl > o_zmax) ? 1.f : (zl < o_zmin) ? -1.f : 0.f;
-    f.z_lo = (zl > o_zmax) ? o_zmin - margin : -3.0e38f;
-    f.z_hi = (zl < o_zmin) ? o_zmax + margin : 3.0e38f;
+    f.z_lo = (zl > o_zmax) ? o_zmin : -3.0e38f;
+    f.z_hi = (zl < o_zmin) ? o_zmax : 3.0e38f;
+    f.margin = margin;
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         const f3 o = w ? o_last : o_first;
@@ -84,35 +87,41 @@ __device__ __forceinline__ RayFan make_fan(f3 o_first, f3 o_last, float zl, floa
         f.gy0[w] = 250.f - o.y;
         const float far = fmaxf(fmaxf(fabsf(250.f - o.x), fabsf(750.f - o.x)),
                                 fmaxf(fabsf(250.f - o.y), fabsf(750.f - o.y)));
-        f.thr[w] = margin * 1.0001f * __builtin_amdgcn_sqrtf(f.h[w] * f.h[w] + far * far);
+        const float len = 1.0001f * __builtin_amdgcn_sqrtf(f.h[w] * f.h[w] + far * far);
+        f.thr[w] = margin * len;
+        f.per_thr[w] = (len > 0.f && margin < 1.0e38f) ? 0.9999f / len : 0.f;
     }
     return f;
 }
 
-// True if triangle (v0, v0 + e1, v0 + e2) lies outside the pyramid of all the record's
-// shadow rays: below line 0 or above line 4 in x or in y, or behind the rays in z.
-__device__ __forceinline__ bool outside_fan(const RayFan &f, f3 v0, f3 e1, f3 e2) {
+// Distance (a lower bound of it) by which triangle (v0, v0 + e1, v0 + e2) lies outside the
+// pyramid of all the record's shadow rays: below line 0 or above line 4 in x or in y, or behind
+// the rays in z; the triangle is outside_fan when it exceeds the margin.  Finite coordinates only.
+__device__ __forceinline__ float fan_separation(const RayFan &f, f3 v0, f3 e1, f3 e2) {
     const f3 v[3] = {v0, f3_add(v0, e1), f3_add(v0, e2)};
-    bool out = (v[0].z < f.z_lo) & (v[1].z < f.z_lo) & (v[2].z < f.z_lo);
-    out |= (v[0].z > f.z_hi) & (v[1].z > f.z_hi) & (v[2].z > f.z_hi);
-    if (f.sigma == 0.f) return out;
-    bool xb = true, xa = true, yb = true, ya = true;
+    float sep = fmaxf(f.z_lo - fmaxf(fmaxf(v[0].z, v[1].z), v[2].z), fminf(fminf(v[0].z, v[1].z), v[2].z) - f.z_hi);
+    if (f.sigma == 0.f) return sep;
+    float xb = 3.0e38f, xa = 3.0e38f, yb = 3.0e38f, ya = 3.0e38f; // smallest distance beyond each face
 #pragma unroll
     for (int w = 0; w < 2; w++) {
-        const float lo = -f.thr[w], hi = f.thr[w];
+        float gx_max = -3.0e38f, gy_max = -3.0e38f, gx_min = 3.0e38f, gy_min = 3.0e38f;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const float dz = f.sigma * v[j].z - f.soz[w];
             const float t = 500.f * dz;
             const float gx = f.h[w] * (v[j].x - f.ox[w]) - f.gx0[w] * dz;
             const float gy = f.h[w] * (v[j].y - f.oy[w]) - f.gy0[w] * dz;
-            xb = xb && gx < lo;
-            yb = yb && gy < lo;
-            xa = xa && (gx - t) > hi; // line 4: X + 500
-            ya = ya && (gy - t) > hi;
+            gx_max = fmaxf(gx_max, gx);
+            gy_max = fmaxf(gy_max, gy);
+            gx_min = fminf(gx_min, gx - t); // line 4: X + 500
+            gy_min = fminf(gy_min, gy - t);
         }
+        xb = fminf(xb, -gx_max * f.per_thr[w]);
+        yb = fminf(yb, -gy_max * f.per_thr[w]);
+        xa = fminf(xa, gx_min * f.per_thr[w]);
+        ya = fminf(ya, gy_min * f.per_thr[w]);
     }
-    return out || xb || xa || yb || ya;
+    return fmaxf(sep, fmaxf(fmaxf(xb, xa), fmaxf(yb, ya)));
 }
 
 // Cells of the light whose rays may hit a triangle that is not outside_fan.
@@ -160,39 +169,70 @@ __device__ __forceinline__ uint32_t cell_mask(const RayFan &f, f3 v0, f3 e1, f3 
 }
 
 // Screens the n <= CAND_MAX primitives of the leaf: offsets inside the leaf of those that
-// are not outside_fan, in order, to L.cand.  Returns how many.
+// are not outside_fan, in order, to L.cand.  Returns how many.  G (may be null: nothing is
+// dropped then): the record's grazing guard, see shade_record.h; a triangle it keeps for every
+// sample carries FULL_MASK in its list entry.
+#define CAND_FULL_MASK 0x8000u
 __device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFan &fan,
                                                           const DPrim *__restrict__ leaf_prims, uint32_t n,
-                                                          uint32_t lane) {
+                                                          uint32_t lane, const GrazeCtx *G,
+                                                          uint32_t *__restrict__ graze_list, uint32_t &n_graze) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
         bool keep = false;
+        uint32_t code = 0, first = 0, cnt = 0;
         if (t < n) {
             const DPrim *p = leaf_prims + t;
             keep = true;
-            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) keep = !outside_fan(fan, p->a, p->b, p->c);
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                const float sep = fan_separation(fan, p->a, p->b, p->c);
+                keep = !(sep > fan.margin);
+                if (!keep && G) {
+                    code = graze_check(*G, p, sep, first, cnt);
+                    keep = code == 2u;
+                }
+            }
         }
+        if (G) graze_push(graze_list, n_graze, code, t, first, cnt);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            L.cand[pos] = (uint16_t)t;
+            L.cand[pos] = (uint16_t)(t | (code == 2u ? CAND_FULL_MASK : 0u));
         }
         total += (uint32_t)__popcll(mask);
     }
     return total;
 }
 
-// Cell masks of the n_cand candidates, to L.cells.
+// Cell masks of the n_cand candidates, to L.cells (and the marks on the list entries cleared).
+// A triangle that is left out of some cells goes through the grazing guard like one that is
+// dropped altogether.
 __device__ __forceinline__ void build_cell_masks(SortLds &L, const RayFan &fan,
                                                  const DPrim *__restrict__ leaf_prims, uint32_t n_cand,
-                                                 uint32_t lane) {
-    for (uint32_t c = lane; c < n_cand; c += 64) {
-        const DPrim *p = leaf_prims + L.cand[c];
-        uint32_t cells = 0xFFFFu;
-        if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) cells = cell_mask(fan, p->a, p->b, p->c);
-        L.cells[c] = (uint16_t)cells;
+                                                 uint32_t lane, const GrazeCtx *G, uint32_t *__restrict__ graze_list,
+                                                 uint32_t &n_graze) {
+    for (uint32_t base = 0; base < n_cand; base += 64) {
+        const uint32_t c = base + lane;
+        uint32_t code = 0, first = 0, cnt = 0, t = 0;
+        if (c < n_cand) {
+            const uint32_t entry = L.cand[c];
+            t = entry & (CAND_FULL_MASK - 1u);
+            const DPrim *p = leaf_prims + t;
+            uint32_t cells = 0xFFFFu;
+            if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE && !(entry & CAND_FULL_MASK)) {
+                cells = cell_mask(fan, p->a, p->b, p->c);
+                if (cells != 0xFFFFu && G) {
+                    // (left out of a cell by the margin at least)
+                    code = graze_check(*G, p, fan.margin, first, cnt);
+                    if (code == 2u) cells = 0xFFFFu;
+                }
+            }
+            L.cells[c] = (uint16_t)cells;
+            L.cand[c] = (uint16_t)t;
+        }
+        if (G) graze_push(graze_list, n_graze, code, t, first, cnt);
     }
 }
 
@@ -301,16 +341,40 @@ __device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPr
             // the start points are exactly p0 + k * dlt, k = 1 .. n_lights (closed form)
             f3 o_first, o_last;
             const float margin = screen_segment(true, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
-            const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
+            RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
             PHASE_MARK(0);
-            n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane);
+            const bool screened = margin < 1.0e38f;
+            const GrazeCtx G = graze_ctx(true, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
+            uint32_t *graze_list = L.sample; // (free until the samples are sorted)
+            uint32_t n_graze = 0;
+            n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, screened ? &G : nullptr, graze_list, n_graze);
             PHASE_MARK(1);
             use_sort = n_cand >= SORT_MIN_CAND;
 #ifdef STEP_STATS
             tot.st[8] += use_sort;
 #endif
             wave_lds_sync();
-            if (use_sort) build_cell_masks(L, fan, leaf_prims, n_cand, lane);
+            // (without the sort every candidate is tested in every pass: the marks just go)
+            build_cell_masks(L, fan, leaf_prims, use_sort ? n_cand : 0u, lane, screened ? &G : nullptr, graze_list, n_graze);
+            if (!use_sort)
+                for (uint32_t c = lane; c < n_cand; c += 64) L.cand[c] &= (uint16_t)(CAND_FULL_MASK - 1u);
+            wave_lds_sync();
+#ifdef STEP_STATS
+            tot.st[10] += n_graze;
+            tot.st[11] += n_graze != 0;
+            tot.st[13] += count;
+#endif
+            if (n_graze && graze_resolve(fr, leaf_prims, graze_list, n_graze, p0, dlt, pixel, leaf, k_off, lane)) {
+#ifdef STEP_STATS
+                tot.st[12]++;
+#endif
+                // the float test accepts a pair the screens would drop: this record without screens
+                fan = make_fan(o_first, o_last, fr.light_pos.z, 3.0e38f);
+                wave_lds_sync();
+                n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, nullptr, graze_list, n_graze);
+                wave_lds_sync();
+                build_cell_masks(L, fan, leaf_prims, n_cand, lane, nullptr, graze_list, n_graze);
+            }
         }
         wave_lds_sync();
         PHASE_MARK(2);
