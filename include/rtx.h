@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 2u /* 2: rtx_stats grew render_attempts, record_capacity */
+#define RTX_ABI_VERSION 2u /* 2: rtx_stats grew render_attempts, record_capacity, screen_ms */
 #define RTX_NONE 0xFFFFFFFFu
 
 typedef enum rtx_status {
@@ -182,11 +182,14 @@ typedef struct rtx_stats {
                                geometric screen and cannot affect a result */
     float kernel_ms[4];     /* trace (with the sorting of the hit records into work
                                lists), shadow+shade kernel, merge, total on the stream
-                               (only with RTX_FLAG_TIMING) */
+                               (all kernels, screen_ms included; only with RTX_FLAG_TIMING) */
     uint32_t render_attempts; /* times the frame's kernels ran: 1, or more when the hit
                                records outgrew their buffer and the frame was rendered
                                again into a larger one (first frames of a scene only) */
     uint32_t record_capacity; /* hit records the buffer held on the last attempt */
+    float screen_ms;        /* the kernel that builds the records' candidate lists, between
+                               kernel_ms[0] and kernel_ms[1] (only with RTX_FLAG_TIMING) */
+    uint32_t reserved;
 } rtx_stats;
 
 /* Library / device ----------------------------------------------------------*/
@@ -268,7 +271,7 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
  *   All calls on one GPU share that GPU's array (whatever the scene or
  * stream): calls that overlap in time on one GPU race and give undefined
  * frames; calls on different GPUs are independent. */
-#define RTX_STATIC_SCRATCH_BYTES (64u << 20)
+#define RTX_STATIC_SCRATCH_BYTES (128u << 20)
 #define RTX_STATIC_MIN_RECORDS 4096u
 rtx_status rtx_render_device_static(rtx_scene *scene, const rtx_params *p, void *d_rgb,
                                     void *hip_stream, rtx_stats *stats);

@@ -68,11 +68,12 @@ class Stats(C.Structure):
                 ("shadow_rays", C.c_uint64), ("shadow_tests", C.c_uint64),
                 ("lit_samples", C.c_uint64), ("shadow_tests_run", C.c_uint64),
                 ("kernel_ms", C.c_float * 4),
-                ("render_attempts", C.c_uint32), ("record_capacity", C.c_uint32)]
+                ("render_attempts", C.c_uint32), ("record_capacity", C.c_uint32),
+                ("screen_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(Material) == 32 and C.sizeof(Prim) == 48 and C.sizeof(Node) == 32
-assert C.sizeof(Hit) == 32 and C.sizeof(Stats) == 72
+assert C.sizeof(Hit) == 32 and C.sizeof(Stats) == 80
 
 
 def default_params(width=1000, height=1000, n_lights=1, seed=1):

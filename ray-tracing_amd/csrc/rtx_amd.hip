@@ -7,6 +7,8 @@
 //                    leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
 //   classify_kernel  one lane per hit record: the record goes to the work list of its
 //                    class (how it will be shaded, how heavy its leaf is)
+//   screen_kernel    one wave per hit record, lanes over its leaf: the primitives the
+//                    record's shadow rays can reach at all -> one candidate list per record
 //   shade_kernel     one wave per hit record, lanes over the light samples: shadow
 //                    rays against the record's leaf + BSDF (raytracing.h:36-50,
 //                    shade.h) -> one colour per record   (shade_few_kernel: several
@@ -36,6 +38,7 @@
 #include "bsdf.h"
 #include "shade_record.h"
 #include "shade_sorted.h"
+#include "screen_kernel.h"
 #include "shade_kernels.h"
 #include "merge_kernel.h"
 #include "selftest_kernels.h"
@@ -65,6 +68,8 @@ static rtx_status fail(rtx_status s, const std::string &msg) {
 // array's name is only a handle for hipGetSymbolAddress: the address the kernels get is
 // the one resolved per device in scratch_resolve().
 #define STATIC_SCRATCH_BYTES RTX_STATIC_SCRATCH_BYTES
+#define STATIC_POOL_PER_RECORD 32u // entries of the candidate pool per hit record in the static work area
+#define POOL_PER_RECORD 64u        // first guess for the allocated pool
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
 #define SCRATCH_MAX_DEVICES 64
@@ -92,6 +97,9 @@ struct FrameBufs {
     uint32_t *first = nullptr;
     uint32_t *tiles = nullptr;
     DCounters *ctr = nullptr;
+    // candidate lists of the records: block offset and length per record (rec_cap each), the pool
+    uint32_t *cand_off = nullptr, *cand_n = nullptr, *pool = nullptr;
+    uint32_t pool_cap = 0;
 };
 
 struct rtx_scene {
@@ -113,6 +121,9 @@ struct rtx_scene {
     uint64_t n_hits = 0; // hit records of the last frame
     float4 *d_colors = nullptr;
     uint32_t rec_cap = 0;
+    uint32_t *d_cand = nullptr; // rec_cap block offsets, then rec_cap list lengths
+    uint32_t *d_pool = nullptr; // the candidate lists
+    uint64_t pool_cap = 0;
     uint32_t *d_first = nullptr;
     uint64_t pix_cap = 0;
     uint32_t *d_tiles = nullptr; // tile queues of the trace kernel, then one flag byte per tile part
@@ -122,7 +133,7 @@ struct rtx_scene {
     uint64_t rgb_cap = 0;
     DCounters *d_ctr = nullptr;
     DCounters *h_ctr = nullptr; // pinned
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 extern "C" uint32_t rtx_abi_version(void) { return RTX_ABI_VERSION; }
@@ -254,6 +265,8 @@ extern "C" void rtx_scene_destroy(rtx_scene *s) {
     (void)hipFree(s->d_mats);
     (void)hipFree(s->d_recs);
     (void)hipFree(s->d_colors);
+    (void)hipFree(s->d_cand);
+    (void)hipFree(s->d_pool);
     (void)hipFree(s->d_first);
     (void)hipFree(s->d_rgb);
     (void)hipFree(s->d_tiles);
@@ -462,7 +475,7 @@ extern "C" rtx_status rtx_scene_create(const rtx_scene_desc *desc, int device, r
     if (e == hipSuccess) e = up((void **)&s->d_mats, mats.data(), mats.size() * sizeof(DMat));
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(DCounters));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctr, sizeof(DCounters), hipHostMallocDefault);
-    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
+    for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
     if (e != hipSuccess) {
         rtx_scene_destroy(s);
         return fail(e == hipErrorOutOfMemory ? RTX_ERR_NOMEM : RTX_ERR_HIP,
@@ -515,13 +528,16 @@ static rtx_status ensure_records(rtx_scene *s, uint64_t need) {
     if (need > 0xFFFFFFF0ull) return fail(RTX_ERR_LIMIT, "more than 2^32 hit records in one call");
     (void)hipFree(s->d_recs);
     (void)hipFree(s->d_colors);
+    (void)hipFree(s->d_cand);
     s->d_recs = nullptr;
     s->d_colors = nullptr;
+    s->d_cand = nullptr;
     s->rec_cap = 0;
     hipError_t e = hipMalloc((void **)&s->d_recs, need * sizeof(DRec));
     // the colours are followed by the work lists of the shading kernel
     if (e == hipSuccess)
         e = hipMalloc((void **)&s->d_colors, need * (sizeof(float4) + N_CLASSES * sizeof(uint32_t)));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_cand, need * 2 * sizeof(uint32_t));
     if (e != hipSuccess) return fail(RTX_ERR_NOMEM, std::string("record buffers: ") + hipGetErrorString(e));
     s->rec_cap = (uint32_t)need;
     return RTX_OK;
@@ -679,6 +695,12 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (queued)
             if (hipError_t e = grow(&s->d_tiles, &s->tile_cap, plan.words); e != hipSuccess)
                 return fail(RTX_ERR_NOMEM, std::string("tile queues: ") + hipGetErrorString(e));
+        // the candidate pool: one entry per primitive of every record's leaf.  A first guess of
+        // POOL_PER_RECORD per record (the reference's meshes average 20 to 70); a frame that needs
+        // more is rendered again with what it needs.
+        if (p->n_lights > 32 || (p->flags & RTX_FLAG_WAVE_PER_HIT))
+            if (hipError_t e = grow(&s->d_pool, &s->pool_cap, (uint64_t)s->rec_cap * POOL_PER_RECORD); e != hipSuccess)
+                return fail(RTX_ERR_NOMEM, std::string("candidate pool: ") + hipGetErrorString(e));
     }
     FrameBufs wb;
     if (fixed) {
@@ -686,6 +708,8 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     } else {
         wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
         wb.first = s->d_first, wb.tiles = s->d_tiles, wb.ctr = s->d_ctr;
+        wb.cand_off = s->d_cand, wb.cand_n = s->d_cand + s->rec_cap, wb.pool = s->d_pool;
+        wb.pool_cap = (uint32_t)std::min<uint64_t>(s->pool_cap, 0xFFFFFFFFu);
     }
     const bool timing = stats && (p->flags & RTX_FLAG_TIMING);
     uint8_t *d_traced = queued ? reinterpret_cast<uint8_t *>(wb.tiles + (uint64_t)tile_seg * TILE_QUEUES) : nullptr;
@@ -746,12 +770,17 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     } while (0)
 #define LAUNCH_SHADE(B, I, W)                                                                                \
     shade_kernel<B, I, W><<<(B) ? bounce_blocks : shade_blocks, SHADE_BLOCK, 0, st>>>(                       \
-        fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, wb.ctr)
+        fr, s->d_prims, s->d_mats, wb.recs, wb.rec_cap, wb.colors, lists, wb.ctr)
+        const CandLists lists = {wb.pool, wb.cand_off, wb.cand_n};
         const uint32_t nlg = p->n_lights;
         const bool ieee = (p->flags & RTX_FLAG_IEEE_SHADE) != 0;
         const bool few = nlg <= 32 && !(p->flags & RTX_FLAG_WAVE_PER_HIT);
         if (!few)
-            classify_kernel<<<few_blocks, 256, 0, st>>>(fr, wb.recs, wb.rec_cap, wb.colors, wb.ctr);
+            classify_kernel<<<few_blocks, 256, 0, st>>>(fr, wb.recs, wb.rec_cap, wb.colors, wb.cand_off, wb.ctr);
+        if (timing) HIP_TRY(hipEventRecord(s->ev[4], st));
+        if (!few)
+            screen_kernel<<<few_blocks, SCREEN_BLOCK, 0, st>>>(fr, s->d_prims, wb.recs, wb.rec_cap, wb.cand_off, wb.cand_n,
+                                                               wb.pool, wb.pool_cap, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
         if (few) {
             // few samples: several hit records per wave
@@ -793,7 +822,21 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
             fullest = std::max(fullest, s->h_ctr->shard[k].count);
             n_hits += s->h_ctr->shard[k].count;
         }
-        if (fullest <= wb.rec_cap / REC_SHARDS) break;
+        const uint64_t pool_need = few ? 0 : s->h_ctr->cand_total;
+        const bool recs_fit = fullest <= wb.rec_cap / REC_SHARDS, pool_fits = pool_need <= wb.pool_cap;
+        if (recs_fit && pool_fits) break;
+        if (fixed && recs_fit)
+            return fail(RTX_ERR_LIMIT, "the frame's candidate lists (" + std::to_string(pool_need) +
+                                           " entries) exceed what the static work area holds for them (" +
+                                           std::to_string(wb.pool_cap) + "); use rtx_render_device");
+        if (recs_fit) { // only the candidate pool was too small: now its size is known
+            if (attempt == 2) return fail(RTX_ERR_HIP, "candidate pool overflow persisted");
+            if (pool_need > 0xFFFFFFF0ull) return fail(RTX_ERR_LIMIT, "more than 2^32 candidate list entries in one call");
+            if (hipError_t e = grow(&s->d_pool, &s->pool_cap, pool_need + pool_need / 8 + 1024); e != hipSuccess)
+                return fail(RTX_ERR_NOMEM, std::string("candidate pool: ") + hipGetErrorString(e));
+            wb.pool = s->d_pool, wb.pool_cap = (uint32_t)std::min<uint64_t>(s->pool_cap, 0xFFFFFFFFu);
+            continue;
+        }
         // a shard got more hits than it holds
         if (fixed)
             return fail(RTX_ERR_LIMIT, "the frame has more hit records (" + std::to_string(n_hits) +
@@ -805,6 +848,12 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         rs = ensure_records(s, ((uint64_t)fullest + fullest / 8 + 128) * REC_SHARDS);
         if (rs != RTX_OK) return rs;
         wb.recs = s->d_recs, wb.colors = s->d_colors, wb.rec_cap = s->rec_cap;
+        wb.cand_off = s->d_cand, wb.cand_n = s->d_cand + s->rec_cap;
+        if (!few) {
+            if (hipError_t e = grow(&s->d_pool, &s->pool_cap, (uint64_t)s->rec_cap * POOL_PER_RECORD); e != hipSuccess)
+                return fail(RTX_ERR_NOMEM, std::string("candidate pool: ") + hipGetErrorString(e));
+            wb.pool = s->d_pool, wb.pool_cap = (uint32_t)std::min<uint64_t>(s->pool_cap, 0xFFFFFFFFu);
+        }
     }
 #ifdef PHASE_TIMES
     {
@@ -841,7 +890,10 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         stats->render_attempts = attempts;
         stats->record_capacity = wb.rec_cap;
         if (timing) {
-            for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
+            // [0] tile list, trace, classify; screen_ms the candidate screens; [1] the shading kernel(s); [2] merge
+            HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[0], s->ev[0], s->ev[4]));
+            HIP_TRY(hipEventElapsedTime(&stats->screen_ms, s->ev[4], s->ev[1]));
+            for (int k = 1; k < 3; k++) HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[k], s->ev[k], s->ev[k + 1]));
             HIP_TRY(hipEventElapsedTime(&stats->kernel_ms[3], s->ev[0], s->ev[3]));
         }
     }
@@ -873,7 +925,10 @@ extern "C" rtx_status rtx_render_device_static(rtx_scene *s, const rtx_params *p
     auto round256 = [](uint64_t b) { return (b + 255u) & ~(uint64_t)255u; };
     const uint64_t ctr_bytes = round256(sizeof(DCounters)), first_bytes = round256(npix * sizeof(uint32_t)),
                    tile_bytes = round256(plan.words * sizeof(uint32_t));
-    const uint64_t per_rec = sizeof(DRec) + sizeof(float4) + N_CLASSES * sizeof(uint32_t);
+    // per record: the record, its colour, its entries in the work lists, offset and length of its
+    // candidate list, and STATIC_POOL_PER_RECORD entries of the candidate pool
+    const uint64_t per_rec = sizeof(DRec) + sizeof(float4) + N_CLASSES * sizeof(uint32_t) + 2 * sizeof(uint32_t) +
+                             STATIC_POOL_PER_RECORD * sizeof(uint32_t);
     const uint64_t fixed_bytes = ctr_bytes + first_bytes + tile_bytes;
     const uint64_t rec_cap = fixed_bytes < STATIC_SCRATCH_BYTES
                                  ? ((STATIC_SCRATCH_BYTES - fixed_bytes) / per_rec) & ~(uint64_t)(4 * REC_SHARDS - 1)
@@ -890,6 +945,11 @@ extern "C" rtx_status rtx_render_device_static(rtx_scene *s, const rtx_params *p
     B.recs = reinterpret_cast<DRec *>(base + fixed_bytes);
     B.rec_cap = (uint32_t)std::min<uint64_t>(rec_cap, 0xFFFFFFF0u & ~(uint32_t)(4 * REC_SHARDS - 1));
     B.colors = reinterpret_cast<float4 *>(base + fixed_bytes + (uint64_t)B.rec_cap * sizeof(DRec));
+    B.cand_off = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(B.colors) +
+                                              (uint64_t)B.rec_cap * (sizeof(float4) + N_CLASSES * sizeof(uint32_t)));
+    B.cand_n = B.cand_off + B.rec_cap;
+    B.pool = B.cand_n + B.rec_cap;
+    B.pool_cap = (uint32_t)std::min<uint64_t>((uint64_t)B.rec_cap * STATIC_POOL_PER_RECORD, 0xFFFFFFFFu);
     return render_frame(s, p, (uint8_t *)d_rgb, (hipStream_t)hip_stream, stats, &B);
 }
 

@@ -123,7 +123,8 @@ struct DTileRects {
 #define QUEUE_HEADS 64u // queue heads per work list (a power of two, at most 64: one per lane)
 #endif
 struct DCounters {
-    uint32_t pad0[2];
+    uint32_t cand_total; // entries of the candidate pool handed out to the records (classify_kernel)
+    uint32_t pad0;
     unsigned long long leaf_prims; // sum of the leaf sizes over all records
     unsigned long long lit;        // light samples that were not occluded
     unsigned long long tests_run;  // shadow-ray primitive tests executed

@@ -12,6 +12,7 @@
 #endif
 __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__restrict__ recs,
                                                         uint32_t rec_cap, float4 *__restrict__ colors,
+                                                        uint32_t *__restrict__ cand_off,
                                                         DCounters *__restrict__ ctr) {
     const RecMap map = rec_map(ctr, rec_cap); // final: written by the previous kernel
     const uint32_t n_recs = map.total;
@@ -20,22 +21,45 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t per_wave = 64 * CLASSIFY_PER_LANE;
     for (uint32_t base = wave_id * per_wave; base < n_recs; base += n_waves * per_wave) {
-        uint32_t cls[CLASSIFY_PER_LANE];
+        uint32_t cls[CLASSIFY_PER_LANE], leaf_size[CLASSIFY_PER_LANE];
+        uint32_t lane_sum = 0;
 #pragma unroll
         for (int g = 0; g < CLASSIFY_PER_LANE; g++) {
             const uint32_t i = base + g * 64 + lane;
             cls[g] = N_CLASSES; // none
+            leaf_size[g] = 0;
             if (i < n_recs) {
                 const DRec *rc = recs + rec_index(map, i);
                 const uint32_t count = rc->count;
-                bool sorted = false;
+                bool closed = false;
                 if (fr.sort_samples && count >= SORT_MIN_LEAF && count <= CAND_MAX) {
                     float dlt;
-                    sorted = acne_chain_delta(rc->px, rc->nx * fr.acne, fr.n_lights, dlt) &&
+                    closed = acne_chain_delta(rc->px, rc->nx * fr.acne, fr.n_lights, dlt) &&
                              acne_chain_delta(rc->py, rc->ny * fr.acne, fr.n_lights, dlt) &&
                              acne_chain_delta(rc->pz, rc->nz * fr.acne, fr.n_lights, dlt);
                 }
-                cls[g] = (sorted ? CLASS_SORTED : CLASS_PLAIN) + weight_group(count);
+                cls[g] = (record_sorts(fr, count, closed) ? CLASS_SORTED : CLASS_PLAIN) + weight_group(count);
+                leaf_size[g] = count;
+                lane_sum += count;
+            }
+        }
+        // a block of the candidate pool for every record, as many entries as its leaf has
+        // primitives: one atomic for the wave's 512 records, a scan for the rest
+        {
+            uint32_t incl = lane_sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= (uint32_t)off) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            uint32_t first = 0;
+            if (lane == 0 && total) first = atomicAdd(&ctr->cand_total, total);
+            uint32_t run = __builtin_amdgcn_readfirstlane(first) + (incl - lane_sum);
+#pragma unroll
+            for (int g = 0; g < CLASSIFY_PER_LANE; g++) {
+                if (cls[g] != N_CLASSES) cand_off[rec_index(map, base + g * 64 + lane)] = run;
+                run += leaf_size[g];
             }
         }
 #pragma unroll
@@ -76,7 +100,7 @@ __global__ __launch_bounds__(256) void classify_kernel(DFrame fr, const DRec *__
 template <bool SORTED, bool BOUNCE, bool IEEE>
 __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const DPrim *__restrict__ prims,
                                            const DMat *__restrict__ mats, const DRec *__restrict__ recs,
-                                           uint32_t rec_cap, float4 *__restrict__ colors,
+                                           uint32_t rec_cap, float4 *__restrict__ colors, const CandLists &lists,
                                            DCounters *__restrict__ ctr, ShadeLds &LP, SortLds &LS, BounceLds &B,
                                            uint32_t lane, ShadeTotals &tot) {
     const uint32_t n = ctr->cls[cls].count; // final: written by classify_kernel
@@ -114,9 +138,9 @@ __device__ __forceinline__ void drain_list(uint32_t cls, const DFrame &fr, const
             if (e >= n) break;
             const uint32_t ridx = list[e];
             if constexpr (SORTED)
-                shade_record_sorted<IEEE>(fr, prims, mats, recs, colors, LS, lane, ridx, tot);
+                shade_record_sorted<IEEE>(fr, prims, mats, recs, colors, lists, LS, lane, ridx, tot);
             else
-                shade_record<BOUNCE, IEEE>(fr, prims, mats, recs, colors, LP, LS, B, lane, ridx, tot);
+                shade_record<BOUNCE, IEEE>(fr, prims, mats, recs, colors, lists, LP, LS, B, lane, ridx, tot);
         }
     }
 }
@@ -127,7 +151,7 @@ template <bool BOUNCE, bool IEEE, int WAVES>
 __global__ __launch_bounds__(SHADE_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void shade_kernel(
     DFrame fr, const DPrim *__restrict__ prims, const DMat *__restrict__ mats,
-    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors,
+    const DRec *__restrict__ recs, uint32_t rec_cap, float4 *__restrict__ colors, CandLists lists,
     DCounters *__restrict__ ctr) {
     __shared__ union {
         ShadeLds plain;
@@ -145,10 +169,10 @@ void shade_kernel(
         const uint32_t w = step >> 1; // weight group; within it plain before sorted
         const uint32_t cls = (step & 1u) ? CLASS_SORTED + w : CLASS_PLAIN + w;
         if (cls < CLASS_PLAIN && !BOUNCE) {
-            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain,
+            drain_list<true, false, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, lists, ctr, lds[wave].plain,
                                           lds[wave].sorted, levels[0], lane, tot);
         } else { // (the kernel of the mirror bounces takes every list the same way)
-            drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, ctr, lds[wave].plain,
+            drain_list<false, BOUNCE, IEEE>(cls, fr, prims, mats, recs, rec_cap, colors, lists, ctr, lds[wave].plain,
                                             lds[wave].sorted, levels[BOUNCE ? wave : 0], lane, tot);
         }
     }
@@ -161,7 +185,7 @@ void shade_kernel(
         for (int k = 0; k < 8; k++) atomicAdd(out + k, tot.st[k]);
         if (atomicMax(out + 8, tot.st[8]) < tot.st[8]) out[9] = tot.st[9]; // (the longest record; racy, good enough)
 #else
-        for (int k = 0; k < 14; k++) atomicAdd(out + k, tot.st[k]);
+        for (int k = 0; k < 10; k++) atomicAdd(out + k, tot.st[k]);
 #endif
     }
 #endif

@@ -216,22 +216,25 @@ __device__ __forceinline__ float pyramid_separation(const ShadeLds &L, f3 v0, f3
 // form an arithmetic sequence: at most a few consecutive samples can be within rho (rho is
 // below a sample's step in the usual case).  graze_check() finds them for every triangle a
 // screen is about to drop: none - dropping is safe; more than GRAZE_KMAX, or anything that
-// cannot be bounded (a triangle without area, start points off the segment because the acne
-// chain has no closed form, coordinates so large that m is within rounding) - the triangle
+// cannot be bounded (a triangle without area, coordinates so large that m is within
+// rounding) - the triangle
 // is kept for every sample; else the (triangle, sample) pairs go to a list, and
-// graze_resolve() looks at each pair's ray: if it is within A_max of parallel to the triangle's
-// plane as well, the record is shaded without screens.  m is half the frame's screen margin: a quarter of that margin
+// graze_resolve() runs the float test itself on each of them: if it accepts one, the record
+// is shaded without screens.  m is half the frame's screen margin: a quarter of that margin
 // is the screens' own rounding (screen_margin()), and the rest covers s' against o - v0.
 #define GRAZE_EPS 6.1e-8f // 2^-24 and room for the higher-order terms
-#define GRAZE_KMAX 2u
-#define GRAZE_LIST 256u   // pairs per record; a record with more is shaded without screens
+#define GRAZE_KMAX 8u
+#define GRAZE_LIST 256u   // pairs per level screened inside the shading kernel (bounce levels); more: no screens
 
 struct GrazeCtx {
-    f3 o1, on;    // first and last start point of the level
+    f3 o1, on;    // ends of the segment the screens were built on (screen_segment)
     float steps;  // n_lights - 1
+    // sample k0 starts at o1 + (k0 + k_add) / k_den * (on - o1): the closed form's segment runs
+    // from the first to the last start point, the other from the hit position to one step
+    // beyond the last
+    float k_add, k_den, per_k_den;
     float m4;     // screen margin / 4
     float drift;  // bound on a start point's distance from the segment (0 with the closed form)
-    bool closed;
 };
 __device__ __forceinline__ GrazeCtx graze_ctx(bool closed, f3 o_first, f3 o_last, uint32_t n_lights, float base_margin,
                                               float margin) {
@@ -239,9 +242,11 @@ __device__ __forceinline__ GrazeCtx graze_ctx(bool closed, f3 o_first, f3 o_last
     g.o1 = o_first;
     g.on = o_last;
     g.steps = (float)(n_lights > 0 ? n_lights - 1u : 0u);
+    g.k_add = closed ? 0.f : 1.f;
+    g.k_den = closed ? g.steps : (float)n_lights + 1.f;
+    g.per_k_den = (g.k_den > 0.f) ? 1.f / g.k_den : 0.f;
     g.m4 = 0.25f * base_margin;
     g.drift = closed ? 0.f : margin - base_margin; // what screen_segment added for the chain's rounding
-    g.closed = closed;
     return g;
 }
 
@@ -252,23 +257,28 @@ __device__ __forceinline__ GrazeCtx graze_ctx(bool closed, f3 o_first, f3 o_last
 __device__ __forceinline__ uint32_t graze_check(const GrazeCtx &g, const DPrim *__restrict__ p, float sep,
                                                 uint32_t &first, uint32_t &count) {
     const f3 s1 = f3_sub(g.o1, p->a), sn = f3_sub(g.on, p->a);
-    const float sig = __builtin_sqrtf(fmaxf(f3_dot(s1, s1), f3_dot(sn, sn))) * 1.001f;
+    // (the hardware's square root and reciprocals, 1 ulp: the factors 1.001 and 1.05 cover them)
+    const float sig = __builtin_amdgcn_sqrtf(fmaxf(f3_dot(s1, s1), f3_dot(sn, sn))) * 1.001f;
     if (!(GRAZE_EPS * 5.f * sig <= g.m4)) return 2u; // (a NaN ends here too)
     // m: the separation less the start points' distance from the segment, the screens' own
     // rounding (a quarter of the margin) and s' against o - v0 (the check above: another quarter)
     const float m = sep - g.drift - 2.f * g.m4;
     if (!(m >= 2.f * g.m4)) return 2u;
-    const float rho = GRAZE_EPS * sig * (p->shape * (29.f * (sig + p->ell) / m + 19.4f) + 8.f) * 1.05f + g.drift + 1.0e-30f;
+    const float rho =
+        GRAZE_EPS * sig * (p->shape * (29.f * (sig + p->ell) * __builtin_amdgcn_rcpf(m) + 19.4f) + 8.f) * 1.05f + g.drift + 1.0e-30f;
     const float h1 = f3_dot(p->n, s1), hn = f3_dot(p->n, sn);
     if ((h1 > rho && hn > rho) || (h1 < -rho && hn < -rho)) return 0u;
-    if (!g.closed) return 2u;
-    // distance of start point k0 from the plane: h1 + k0 * dh, k0 = 0 .. steps
-    const float dh = (g.steps > 0.f) ? (hn - h1) / g.steps : 0.f;
+    // distance of sample k0's start point from the plane: h1 + (k0 + k_add) * dh, k0 = 0 .. steps
+    const float dh = (g.k_den > 0.f) ? (hn - h1) * g.per_k_den : 0.f;
     float lo = 0.f, hi = g.steps;
     if (dh != 0.f) {
-        const float x = (-rho - h1) / dh, y = (rho - h1) / dh;
-        lo = fmaxf(__builtin_ceilf(fminf(x, y) - 0.01f), 0.f);
-        hi = fminf(__builtin_floorf(fmaxf(x, y) + 0.01f), g.steps);
+        // (the interval is widened by 0.02 + 1e-5 of its ends: more than the reciprocal's rounding
+        // and that of h1 + k dh can move them)
+        const float per_dh = __builtin_amdgcn_rcpf(dh);
+        const float x = (-rho - h1) * per_dh - g.k_add, y = (rho - h1) * per_dh - g.k_add;
+        const float slack = 0.02f + 1.0e-5f * fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
+        lo = fmaxf(__builtin_ceilf(fminf(x, y) - slack), 0.f);
+        hi = fminf(__builtin_floorf(fmaxf(x, y) + slack), g.steps);
     } else if (!(__builtin_fabsf(h1) <= rho)) {
         return (h1 == h1) ? 0u : 2u;
     }
@@ -281,64 +291,88 @@ __device__ __forceinline__ uint32_t graze_check(const GrazeCtx &g, const DPrim *
 }
 
 // Appends the pairs of the lanes with code == 1 to the record's list (entry: primitive offset
-// in the leaf | sample << 16).  All lanes of the wave take part.
-__device__ __forceinline__ void graze_push(uint32_t *__restrict__ list, uint32_t &n_list, uint32_t code,
+// in the leaf | sample << 16), in lane order.  All lanes of the wave take part.
+__device__ __forceinline__ void graze_push(uint32_t *__restrict__ list, uint32_t cap, uint32_t &n_list, uint32_t code,
                                            uint32_t prim, uint32_t first, uint32_t count) {
+#ifdef GRAZE_SKIP_PUSH
+    return;
+#endif
+    const uint32_t mine = (code == 1u) ? count : 0u;
+    if (!__any(mine != 0u)) return;
+    uint32_t incl = mine;
 #pragma unroll
-    for (uint32_t r = 0; r < GRAZE_KMAX; r++) {
-        const bool push = code == 1u && r < count;
-        const unsigned long long mask = __ballot(push);
-        if (mask == 0) continue;
-        if (push) {
-            const uint32_t pos = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (pos < GRAZE_LIST) list[pos] = prim | ((first + r) << 16);
-        }
-        n_list += (uint32_t)__popcll(mask);
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((threadIdx.x & 63u) >= (uint32_t)off) incl += up;
     }
+    const uint32_t pos = n_list + incl - mine;
+    for (uint32_t r = 0; r < mine; r++)
+        if (pos + r < cap) list[pos + r] = prim | ((first + r) << 16);
+    n_list += __shfl(incl, 63);
 }
 
-// The listed pairs, one per lane: the sample's ray can only be accepted by the float test if
-// it is within A_max of parallel to the triangle's plane (first part of the argument above:
-// acceptance needs |A~| <= A_max = 29 eps sigma a b / m; here with a b <= (ell / 2)^2, m at its
-// smallest, half the screen margin, and 7 eps a b more for A~ against the value computed
-// here).  Tested on the direction before it is normalised, D = light - start point:
-// |e1 . (D x e2)| > A_max |D| clears the pair.  True if a pair is not cleared, or the list
-// overflowed: the record is then shaded without screens (a few records in a thousand).
+// The float test itself on the listed pairs, one per lane, exactly as the sample loop runs it
+// (same start point - the closed form, or the running sum of raytracing.h:40 step by step -
+// same light sample, same direction).  True if any pair is accepted, or the list overflowed:
+// the record is then shaded without screens (a few dozen records of a 4K frame).
 __device__ __forceinline__ bool graze_resolve(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
-                                              const uint32_t *__restrict__ list, uint32_t n_list, f3 p0, f3 dlt,
-                                              uint32_t pixel, uint32_t leaf, uint32_t k_off, uint32_t lane) {
-    if (n_list > GRAZE_LIST) return true;
-    const float per_m = 2.f / (0.5f * fr.cull_margin); // (half the margin, and half of that again as in graze_check)
+                                              const uint32_t *__restrict__ list, uint32_t cap, uint32_t n_list,
+                                              bool closed, f3 p0, f3 step, f3 dlt, uint32_t pixel, uint32_t leaf,
+                                              uint32_t k_off, uint32_t lane) {
+#ifdef GRAZE_SKIP_RESOLVE
+    return false;
+#endif
+    if (n_list > cap) return true;
+    // Nearly all pairs are cleared by the first part of the argument above alone: acceptance needs
+    // |A~| <= A_max = 29 eps sigma a b / m, here with a b <= (ell / 2)^2, m at its smallest (half
+    // the screen margin, and half of that as in graze_check) and 7 eps a b for A~ against the value
+    // computed here, tested on the direction before it is normalised: |e1 . (D x e2)| > A_max |D|.
+    // Only a pair that is not cleared that way goes through the float test.
+    const float per_m = 4.f / fr.cull_margin;
     for (uint32_t base = 0; base < n_list; base += 64) {
         bool open = false;
+        f3 o = p0, D = p0;
+        const DPrim *__restrict__ p = leaf_prims;
         if (base + lane < n_list) {
             const uint32_t w = list[base + lane], k0 = w >> 16;
-            const DPrim *__restrict__ p = leaf_prims + (w & 0xFFFFu);
-            const float s = (float)(k0 + 1u);
-            const f3 o = f3_make(p0.x + s * dlt.x, p0.y + s * dlt.y, p0.z + s * dlt.z);
+            p = leaf_prims + (w & 0xFFFFu);
+            if (closed) {
+                const float s = (float)(k0 + 1u);
+                o = f3_make(p0.x + s * dlt.x, p0.y + s * dlt.y, p0.z + s * dlt.z);
+            } else {
+                for (uint32_t k = 0; k <= k0; k++) o = f3_add(o, step);
+            }
             f3 l = fr.light_pos;
             light_sample(fr.seed, pixel, leaf, k_off + k0, l.x, l.y);
-            const f3 D = f3_sub(l, o), sv = f3_sub(o, p->a);
+            D = f3_sub(l, o);
+            const f3 sv = f3_sub(o, p->a);
             const float A = f3_dot(p->b, f3_cross(D, p->c));
-            const float sig = __builtin_sqrtf(f3_dot(sv, sv)) * 1.001f, ab = 0.25f * p->ell * p->ell;
+            const float sig = __builtin_amdgcn_sqrtf(f3_dot(sv, sv)) * 1.001f, ab = 0.25f * p->ell * p->ell;
             const float a_max = GRAZE_EPS * ab * (29.f * sig * per_m + 7.f) * 1.05f;
-            // cleared when A^2 > a_max^2 |D|^2 (a NaN leaves the pair open)
-            open = !(A * A > a_max * a_max * f3_dot(D, D) * 1.001f);
+            open = !(A * A > a_max * a_max * f3_dot(D, D) * 1.001f); // (a NaN leaves the pair open)
         }
-        if (__any(open)) return true;
+        if (__any(open)) {
+            bool accepted = false;
+            if (open) {
+                const f3 d = f3_normalize(D); // raytracing.h:43
+                float t;
+                accepted = tri_hit(o, d, p->a, p->b, p->c, t);
+            }
+            if (__any(accepted)) return true;
+        }
     }
     return false;
 }
 
 // Screens primitives [seg, seg + n) of the leaf (n <= CAND_MAX) and writes the
-// survivors' offsets inside the leaf, in order, to L.cand.  Returns how many.  G (may be
+// survivors' offsets inside the leaf (seg + index), in order, to L.cand.  Returns how many.  G (may be
 // null: nothing is dropped then) is the record's grazing guard: the pairs it cannot clear go
 // to graze_list / n_graze.
 __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *__restrict__ leaf_prims,
                                                       uint32_t seg, uint32_t n, uint32_t lane, float z_lo,
                                                       float z_hi, float margin, const GrazeCtx *G,
-                                                      uint32_t *__restrict__ graze_list, uint32_t &n_graze) {
+                                                      uint32_t *__restrict__ graze_list, uint32_t graze_cap,
+                                                      uint32_t &n_graze) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
@@ -356,12 +390,12 @@ __device__ __forceinline__ uint32_t build_candidates(ShadeLds &L, const DPrim *_
                 }
             }
         }
-        if (G) graze_push(graze_list, n_graze, code, seg + t, first, cnt);
+        if (G) graze_push(graze_list, graze_cap, n_graze, code, seg + t, first, cnt);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            L.cand[pos] = (uint16_t)t;
+            L.cand[pos] = (uint16_t)(seg + t);
         }
         total += (uint32_t)__popcll(mask);
     }
@@ -386,6 +420,58 @@ __device__ __forceinline__ float screen_segment(bool closed, f3 p0, f3 step, f3 
                       fmaxf(__builtin_fabsf(p0.z), __builtin_fabsf(o_last.z));
     const float drift = (n + 1.f) * 6.0e-8f * 1.01f * mag; // 2^-24 = 5.96e-8
     return (drift <= 3.f * margin) ? margin + drift : 3.0e38f; // (a NaN drift does not screen either)
+}
+
+// The candidate lists of the hit records as screen_kernel leaves them in device memory (the
+// kernel without mirror bounces reads them; deeper bounce levels screen for themselves).
+// Record r owns pool[cand_off[r] .. + leaf size); cand_n[r] = entries used | CAND_N_SORT when
+// the entries carry cell masks.  Entry: offset of the primitive inside the leaf | cell mask << 16.
+struct CandLists {
+    const uint32_t *__restrict__ pool;
+    const uint32_t *__restrict__ cand_off;
+    const uint32_t *__restrict__ cand_n;
+};
+#define CAND_N_SORT 0x80000000u
+
+// Screens primitives [seg, seg + seg_n) of the leaf for a level whose samples are taken in index
+// order, grazing guard included: the survivors' offsets inside the leaf to L.cand, returns how
+// many.  The faces must have been set up (setup_planes) for the same start points.
+__device__ __forceinline__ uint32_t screen_plain_segment(const DFrame &fr, ShadeLds &L,
+                                                          const DPrim *__restrict__ leaf_prims, uint32_t seg,
+                                                          uint32_t seg_n, uint32_t lane, float z_lo, float z_hi,
+                                                          float margin, bool closed, f3 o_first, f3 o_last, f3 p0,
+                                                          f3 step, f3 dlt, uint32_t pixel, uint32_t leaf,
+                                                          uint32_t k_off, uint32_t *__restrict__ graze_list,
+                                                          uint32_t graze_cap, unsigned long long *stats) {
+    // (a margin no triangle can exceed screens nothing: no guard needed)
+#ifdef NO_GRAZE
+    const bool screened = false; // (measurement build only: the screens without their guard)
+#else
+    const bool screened = margin < 1.0e38f;
+#endif
+    const GrazeCtx G = graze_ctx(closed, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
+    uint32_t n_graze = 0;
+    uint32_t n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, margin, screened ? &G : nullptr,
+                                       graze_list, graze_cap, n_graze);
+    wave_lds_sync();
+#ifdef STEP_STATS
+    if (stats) {
+        stats[10] += n_graze;      // pairs listed
+        stats[11] += n_graze != 0; // records with a list
+        stats[13] += seg_n;        // primitives screened
+    }
+#endif
+    if (n_graze && graze_resolve(fr, leaf_prims, graze_list, graze_cap, n_graze, closed, p0, step, dlt, pixel, leaf, k_off, lane)) {
+#ifdef STEP_STATS
+        if (stats) stats[12]++; // records shaded without screens
+#endif
+        wave_lds_sync();
+        n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, 3.0e38f, nullptr, graze_list, graze_cap,
+                                  n_graze);
+        wave_lds_sync();
+    }
+    (void)stats;
+    return n_cand;
 }
 
 // One hit record, light samples in index order: one wave, lanes over the samples.
@@ -447,11 +533,12 @@ __device__ __forceinline__ void step_stats(ShadeTotals &tot, const ray2 &r, cons
 #endif
 
 struct SortLds;
-template <bool IEEE>
+template <bool IEEE, bool PRE>
 __device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
                                                      uint32_t count, uint32_t pixel, uint32_t leaf, const DMat &mat,
                                                      f3 nrm, f3 p0, f3 view, uint32_t k_off, SortLds &L,
-                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out);
+                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out,
+                                                     const uint32_t *__restrict__ pre, uint32_t pre_n);
 
 // One hit record with its light samples in index order; the BOUNCE build adds the levels
 // of the mirror bounces (raytracing.h:51-61) to the stored sum of the primary level.  LS:
@@ -460,8 +547,9 @@ __device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPr
 template <bool BOUNCE, bool IEEE>
 __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__restrict__ prims,
                                              const DMat *__restrict__ mats, const DRec *__restrict__ recs,
-                                             float4 *__restrict__ colors, ShadeLds &L, SortLds &LS, BounceLds &B,
-                                             uint32_t lane, uint32_t ridx, ShadeTotals &tot) {
+                                             float4 *__restrict__ colors, const CandLists &lists, ShadeLds &L,
+                                             SortLds &LS, BounceLds &B, uint32_t lane, uint32_t ridx,
+                                             ShadeTotals &tot) {
         const float nl = (float)fr.n_lights;
         uint32_t lit_total = 0, bounce_hits = 0;
         unsigned long long bounce_prims = 0, tests_total = 0;
@@ -471,6 +559,13 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel, leaf = rc.leaf, count = rc.count;
         const DPrim *__restrict__ leaf_prims = prims + rc.first;
+        // (build without bounces) the record's candidates, screened by screen_kernel
+        const uint32_t *__restrict__ pre = nullptr;
+        uint32_t pre_n = 0;
+        if constexpr (!BOUNCE) {
+            pre = lists.pool + lists.cand_off[ridx];
+            pre_n = lists.cand_n[ridx] & ~CAND_N_SORT;
+        }
         // state of the current hit: the primary one first, then one per mirror bounce
         // (raytracing.h:51-61; a bounce is traced inside the same leaf)
         DMat mat = mats[rc.mat];
@@ -522,19 +617,22 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
             wave_lds_sync();
         }
 #endif
-        if (!level_done && !level_sorted) setup_planes(L, lane, o_first, o_last, zl);
+        if (BOUNCE && !level_done && !level_sorted) setup_planes(L, lane, o_first, o_last, zl);
         wave_lds_sync();
         PHASE_MARK(0);
-        // a leaf that fits the list is screened once, on the first pass
-        const bool one_segment = count <= CAND_MAX;
+        // What the passes walk: the leaf, screened here in segments of CAND_MAX (bounce build), or
+        // the record's list from screen_kernel, copied to LDS in such segments.  A list that fits is
+        // set up once, on the first pass.
+        const uint32_t seg_total = BOUNCE ? count : pre_n;
+        const bool one_segment = seg_total <= CAND_MAX;
         uint32_t n_cand = 0;
 
         f3 acc = f3_make(0.f, 0.f, 0.f);
         uint32_t lit = 0;
         if (level_sorted) {
             uint32_t lit_s = 0;
-            const float4 sum = shade_level_sorted<IEEE>(fr, leaf_prims, count, pixel, leaf, mat, nrm, p0, view, k_off, LS,
-                                                        lane, tot, lit_s);
+            const float4 sum = shade_level_sorted<IEEE, false>(fr, leaf_prims, count, pixel, leaf, mat, nrm, p0, view, k_off, LS,
+                                                        lane, tot, lit_s, nullptr, 0u);
             acc = f3_make(sum.x, sum.y, sum.z);
             lit = lit_s;
             wave_lds_sync();
@@ -595,31 +693,24 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                 // out of the scene, which lights the sample just as no hit does)
                 float tmin1 = __builtin_inff(), tmin2 = __builtin_inff();
             PHASE_MARK(4);
-            for (uint32_t seg = 0; seg < count; seg += CAND_MAX) {
+            for (uint32_t seg = 0; seg < seg_total; seg += CAND_MAX) {
                 if (!one_segment || base == 0) {
                     wave_lds_sync();
-                    const uint32_t seg_n = min(count - seg, (uint32_t)CAND_MAX);
-                    // (a margin no triangle can exceed screens nothing: no guard needed)
-                    const bool screened = margin < 1.0e38f;
-                    const GrazeCtx G = graze_ctx(closed, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
-                    uint32_t *graze_list = reinterpret_cast<uint32_t *>(L.chain); // (the chain is unused with the closed form,
-                                                                                  //  and only then are pairs listed)
-                    uint32_t n_graze = 0;
-                    n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, margin, screened ? &G : nullptr,
-                                              graze_list, n_graze);
-                    wave_lds_sync();
-#ifdef STEP_STATS
-                    tot.st[10] += n_graze;      // pairs listed
-                    tot.st[11] += n_graze != 0; // records with a list
-                    tot.st[13] += seg_n;        // primitives screened
+                    const uint32_t seg_n = min(seg_total - seg, (uint32_t)CAND_MAX);
+                    if constexpr (BOUNCE) {
+#if defined(STEP_STATS)
+                        unsigned long long *stats = tot.st;
+#else
+                        unsigned long long *stats = nullptr;
 #endif
-                    if (n_graze && graze_resolve(fr, leaf_prims, graze_list, n_graze, p0, dlt, pixel, leaf, k_off, lane)) {
-#ifdef STEP_STATS
-                        tot.st[12]++; // records shaded without screens
-#endif
-                        wave_lds_sync();
-                        n_cand = build_candidates(L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, 3.0e38f, nullptr, graze_list,
-                                                  n_graze);
+                        // (the pairs' list shares LDS with the chain of a level without the closed form:
+                        // such a level lists nothing, and is shaded without screens if it would have to)
+                        n_cand = screen_plain_segment(fr, L, leaf_prims, seg, seg_n, lane, z_lo, z_hi, margin, closed, o_first,
+                                                      o_last, p0, step, dlt, pixel, leaf, k_off,
+                                                      reinterpret_cast<uint32_t *>(L.chain), closed ? GRAZE_LIST : 0u, stats);
+                    } else {
+                        for (uint32_t c = lane; c < seg_n; c += 64) L.cand[c] = (uint16_t)pre[seg + c];
+                        n_cand = seg_n;
                         wave_lds_sync();
                     }
                     PHASE_MARK(1);
@@ -628,11 +719,11 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
                 tests_total += (unsigned long long)n_cand * min(fr.n_lights - base, (uint32_t)PASS_SAMPLES);
                 // walk the list with the next primitive's scalar loads in flight
                 uint32_t ci = __builtin_amdgcn_readfirstlane((uint32_t)L.cand[0]);
-                DPrim cur = leaf_prims[seg + ci];
+                DPrim cur = leaf_prims[ci];
                 for (uint32_t c = 0; c < n_cand; c++) {
                     const uint32_t cn = __builtin_amdgcn_readfirstlane(
                         (uint32_t)L.cand[(c + 1 < n_cand) ? c + 1 : c]);
-                    const DPrim nxt = leaf_prims[seg + cn];
+                    const DPrim nxt = leaf_prims[cn];
                     // the nearest hit so far (raytracing.h:45 takes the smallest distance)
                     const auto nearest = [&](bool hit1, bool hit2, v2f t) {
                         if (hit1 && t.x < tmin1) tmin1 = t.x;

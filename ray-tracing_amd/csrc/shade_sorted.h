@@ -124,32 +124,37 @@ __device__ __forceinline__ float fan_separation(const RayFan &f, f3 v0, f3 e1, f
     return fmaxf(sep, fmaxf(fmaxf(xb, xa), fmaxf(yb, ya)));
 }
 
-// Cells of the light whose rays may hit a triangle that is not outside_fan.
+// Cells of the light whose rays may hit a triangle that is not outside the fan.
 __device__ __forceinline__ uint32_t cell_mask(const RayFan &f, f3 v0, f3 e1, f3 e2) {
     if (f.sigma == 0.f) return 0xFFFFu;
     const f3 v[3] = {v0, f3_add(v0, e1), f3_add(v0, e2)};
-    // xb[i]: the triangle is on the low side of line i (i = 0..3) for every start point;
-    // xa[i]: on the high side of line i + 1
+    // xb[i]: the triangle is on the low side of line i (i = 0..3) for every start point, i.e. the
+    // largest of its vertices' plane functions is below -thr from both ends of the segment;
+    // xa[i]: on the high side of line i + 1 (the smallest above thr)
     bool xb[4] = {true, true, true, true}, xa[4] = {true, true, true, true};
     bool yb[4] = {true, true, true, true}, ya[4] = {true, true, true, true};
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         const float lo = -f.thr[w], hi = f.thr[w];
+        float gx[3], gy[3], t[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const float dz = f.sigma * v[j].z - f.soz[w];
-            const float t = 125.f * dz;
-            float gx = f.h[w] * (v[j].x - f.ox[w]) - f.gx0[w] * dz;
-            float gy = f.h[w] * (v[j].y - f.oy[w]) - f.gy0[w] * dz;
+            t[j] = 125.f * dz;
+            gx[j] = f.h[w] * (v[j].x - f.ox[w]) - f.gx0[w] * dz;
+            gy[j] = f.h[w] * (v[j].y - f.oy[w]) - f.gy0[w] * dz;
+        }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                xb[i] = xb[i] && gx < lo;
-                yb[i] = yb[i] && gy < lo;
-                gx = gx - t; // next line: X + 125
-                gy = gy - t;
-                xa[i] = xa[i] && gx > hi;
-                ya[i] = ya[i] && gy > hi;
+        for (int i = 0; i < 4; i++) {
+            xb[i] = xb[i] && fmaxf(fmaxf(gx[0], gx[1]), gx[2]) < lo;
+            yb[i] = yb[i] && fmaxf(fmaxf(gy[0], gy[1]), gy[2]) < lo;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { // next line: X + 125
+                gx[j] = gx[j] - t[j];
+                gy[j] = gy[j] - t[j];
             }
+            xa[i] = xa[i] && fminf(fminf(gx[0], gx[1]), gx[2]) > hi;
+            ya[i] = ya[i] && fminf(fminf(gy[0], gy[1]), gy[2]) > hi;
         }
     }
     // column c is out if the triangle is below one of the lines 0..c or above one of c+1..4
@@ -168,6 +173,67 @@ __device__ __forceinline__ uint32_t cell_mask(const RayFan &f, f3 v0, f3 e1, f3 
     return mx & my;
 }
 
+// fan_separation and cell_mask in one evaluation of the plane functions (the outer faces of the
+// pyramid are the light's lines 0 and 4): for records that sort their samples.
+__device__ __forceinline__ void fan_screen(const RayFan &f, f3 v0, f3 e1, f3 e2, float &sep_out, uint32_t &cells_out) {
+    const f3 v[3] = {v0, f3_add(v0, e1), f3_add(v0, e2)};
+    float sep = fmaxf(f.z_lo - fmaxf(fmaxf(v[0].z, v[1].z), v[2].z), fminf(fminf(v[0].z, v[1].z), v[2].z) - f.z_hi);
+    sep_out = sep;
+    cells_out = 0xFFFFu;
+    if (f.sigma == 0.f) return;
+    bool xb[4] = {true, true, true, true}, xa[4] = {true, true, true, true};
+    bool yb[4] = {true, true, true, true}, ya[4] = {true, true, true, true};
+    float sxb = 3.0e38f, sxa = 3.0e38f, syb = 3.0e38f, sya = 3.0e38f; // smallest distance beyond each outer face
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const float lo = -f.thr[w], hi = f.thr[w];
+        float gx[3], gy[3], t[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float dz = f.sigma * v[j].z - f.soz[w];
+            t[j] = 125.f * dz;
+            gx[j] = f.h[w] * (v[j].x - f.ox[w]) - f.gx0[w] * dz;
+            gy[j] = f.h[w] * (v[j].y - f.oy[w]) - f.gy0[w] * dz;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float mx = fmaxf(fmaxf(gx[0], gx[1]), gx[2]), my = fmaxf(fmaxf(gy[0], gy[1]), gy[2]);
+            xb[i] = xb[i] && mx < lo;
+            yb[i] = yb[i] && my < lo;
+            if (i == 0) {
+                sxb = fminf(sxb, -mx * f.per_thr[w]);
+                syb = fminf(syb, -my * f.per_thr[w]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) { // next line: X + 125
+                gx[j] = gx[j] - t[j];
+                gy[j] = gy[j] - t[j];
+            }
+            const float nx = fminf(fminf(gx[0], gx[1]), gx[2]), ny = fminf(fminf(gy[0], gy[1]), gy[2]);
+            xa[i] = xa[i] && nx > hi;
+            ya[i] = ya[i] && ny > hi;
+            if (i == 3) {
+                sxa = fminf(sxa, nx * f.per_thr[w]);
+                sya = fminf(sya, ny * f.per_thr[w]);
+            }
+        }
+    }
+    sep_out = fmaxf(sep, fmaxf(fmaxf(sxb, sxa), fmaxf(syb, sya)));
+    const bool x0 = !(xb[0] || xa[0] || xa[1] || xa[2] || xa[3]);
+    const bool x1 = !(xb[0] || xb[1] || xa[1] || xa[2] || xa[3]);
+    const bool x2 = !(xb[0] || xb[1] || xb[2] || xa[2] || xa[3]);
+    const bool x3 = !(xb[0] || xb[1] || xb[2] || xb[3] || xa[3]);
+    const bool y0 = !(yb[0] || ya[0] || ya[1] || ya[2] || ya[3]);
+    const bool y1 = !(yb[0] || yb[1] || ya[1] || ya[2] || ya[3]);
+    const bool y2 = !(yb[0] || yb[1] || yb[2] || ya[2] || ya[3]);
+    const bool y3 = !(yb[0] || yb[1] || yb[2] || yb[3] || ya[3]);
+    const uint32_t mx = (x0 ? HILBERT_X0 : 0u) | (x1 ? HILBERT_X1 : 0u) | (x2 ? HILBERT_X2 : 0u) |
+                        (x3 ? HILBERT_X3 : 0u);
+    const uint32_t my = (y0 ? HILBERT_Y0 : 0u) | (y1 ? HILBERT_Y1 : 0u) | (y2 ? HILBERT_Y2 : 0u) |
+                        (y3 ? HILBERT_Y3 : 0u);
+    cells_out = mx & my;
+}
+
 // Screens the n <= CAND_MAX primitives of the leaf: offsets inside the leaf of those that
 // are not outside_fan, in order, to L.cand.  Returns how many.  G (may be null: nothing is
 // dropped then): the record's grazing guard, see shade_record.h; a triangle it keeps for every
@@ -176,7 +242,8 @@ __device__ __forceinline__ uint32_t cell_mask(const RayFan &f, f3 v0, f3 e1, f3 
 __device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFan &fan,
                                                           const DPrim *__restrict__ leaf_prims, uint32_t n,
                                                           uint32_t lane, const GrazeCtx *G,
-                                                          uint32_t *__restrict__ graze_list, uint32_t &n_graze) {
+                                                          uint32_t *__restrict__ graze_list, uint32_t graze_cap,
+                                                          uint32_t &n_graze) {
     uint32_t total = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t t = base + lane;
@@ -194,7 +261,7 @@ __device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFa
                 }
             }
         }
-        if (G) graze_push(graze_list, n_graze, code, t, first, cnt);
+        if (G) graze_push(graze_list, graze_cap, n_graze, code, t, first, cnt);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const uint32_t pos = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -212,7 +279,7 @@ __device__ __forceinline__ uint32_t build_fan_candidates(SortLds &L, const RayFa
 __device__ __forceinline__ void build_cell_masks(SortLds &L, const RayFan &fan,
                                                  const DPrim *__restrict__ leaf_prims, uint32_t n_cand,
                                                  uint32_t lane, const GrazeCtx *G, uint32_t *__restrict__ graze_list,
-                                                 uint32_t &n_graze) {
+                                                 uint32_t graze_cap, uint32_t &n_graze) {
     for (uint32_t base = 0; base < n_cand; base += 64) {
         const uint32_t c = base + lane;
         uint32_t code = 0, first = 0, cnt = 0, t = 0;
@@ -232,7 +299,7 @@ __device__ __forceinline__ void build_cell_masks(SortLds &L, const RayFan &fan,
             L.cells[c] = (uint16_t)cells;
             L.cand[c] = (uint16_t)t;
         }
-        if (G) graze_push(graze_list, n_graze, code, t, first, cnt);
+        if (G) graze_push(graze_list, graze_cap, n_graze, code, t, first, cnt);
     }
 }
 
@@ -314,17 +381,72 @@ __device__ __forceinline__ void sort_samples(SortLds &L, uint32_t lane, uint32_t
     wave_lds_sync();
 }
 
+// Screens the leaf (count <= CAND_MAX primitives) for a level whose start points have the closed
+// form, grazing guard included: candidates to L.cand, and when there are SORT_MIN_CAND or more
+// (use_sort) their cell masks to L.cells.  Returns the number of candidates.
+__device__ __forceinline__ uint32_t screen_sorted_level(const DFrame &fr, SortLds &L,
+                                                         const DPrim *__restrict__ leaf_prims, uint32_t count,
+                                                         uint32_t lane, f3 o_first, f3 o_last, float margin, f3 p0,
+                                                         f3 dlt, uint32_t pixel, uint32_t leaf, uint32_t k_off,
+                                                         bool &use_sort, unsigned long long *stats) {
+    RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
+#ifdef NO_GRAZE
+    const bool screened = false; // (measurement build only)
+#else
+    const bool screened = margin < 1.0e38f;
+#endif
+    const GrazeCtx G = graze_ctx(true, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
+    uint32_t *graze_list = L.sample; // (free until the samples are sorted)
+    const uint32_t graze_cap = SORT_MAX;
+    uint32_t n_graze = 0;
+    uint32_t n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, screened ? &G : nullptr, graze_list, graze_cap,
+                                           n_graze);
+    use_sort = n_cand >= SORT_MIN_CAND;
+    wave_lds_sync();
+    // (without the sort every candidate is tested in every pass: the marks just go)
+    build_cell_masks(L, fan, leaf_prims, use_sort ? n_cand : 0u, lane, screened ? &G : nullptr, graze_list, graze_cap,
+                     n_graze);
+    if (!use_sort)
+        for (uint32_t c = lane; c < n_cand; c += 64) L.cand[c] &= (uint16_t)(CAND_FULL_MASK - 1u);
+    wave_lds_sync();
+#ifdef STEP_STATS
+    if (stats) {
+        stats[10] += n_graze;
+        stats[11] += n_graze != 0;
+        stats[13] += count;
+    }
+#endif
+    if (n_graze && graze_resolve(fr, leaf_prims, graze_list, graze_cap, n_graze, true, p0, dlt, dlt, pixel, leaf, k_off, lane)) {
+#ifdef STEP_STATS
+        if (stats) stats[12]++;
+#endif
+        // a pair the screens would drop is not cleared: this record without screens
+        fan = make_fan(o_first, o_last, fr.light_pos.z, 3.0e38f);
+        wave_lds_sync();
+        n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, nullptr, graze_list, graze_cap, n_graze);
+        use_sort = n_cand >= SORT_MIN_CAND;
+        wave_lds_sync();
+        build_cell_masks(L, fan, leaf_prims, n_cand, lane, nullptr, graze_list, graze_cap, n_graze);
+        wave_lds_sync();
+    }
+    (void)stats;
+    return n_cand;
+}
+
 // One level of a hit record with sorted light samples (see above): the hit at p0 with
 // normal nrm and material mat, seen along -view, in the leaf leaf_prims[0 .. count); its
 // samples have the sampler's indices k_off .. k_off + n_lights - 1.  Needs n_lights >= 1,
 // a leaf of at most CAND_MAX primitives and the closed form of all three origin components.
+// PRE: the candidates come from the list pre[0 .. pre_n & ~CAND_N_SORT) that screen_kernel wrote
+// (cell masks included when pre_n has CAND_N_SORT); else the level screens the leaf itself.
 // Returns the sum of the samples' contributions (raytracing.h:36-50), the same value in
 // every lane, and the number of lit samples.
-template <bool IEEE>
+template <bool IEEE, bool PRE>
 __device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
                                                      uint32_t count, uint32_t pixel, uint32_t leaf, const DMat &mat,
                                                      f3 nrm, f3 p0, f3 view, uint32_t k_off, SortLds &L,
-                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out) {
+                                                     uint32_t lane, ShadeTotals &tot, uint32_t &lit_out,
+                                                     const uint32_t *__restrict__ pre, uint32_t pre_n) {
         const float nl = (float)fr.n_lights;
         unsigned long long tests_total = 0;
 #ifdef PHASE_TIMES
@@ -337,45 +459,32 @@ __device__ __forceinline__ float4 shade_level_sorted(const DFrame &fr, const DPr
 
         uint32_t n_cand;
         bool use_sort;
-        {
+        if constexpr (PRE) { // the list screen_kernel left for this record (primary level, build without bounces)
+            n_cand = pre_n & ~CAND_N_SORT;
+            use_sort = (pre_n & CAND_N_SORT) != 0;
+            for (uint32_t c = lane; c < n_cand; c += 64) {
+                const uint32_t w = pre[c];
+                L.cand[c] = (uint16_t)w;
+                L.cells[c] = (uint16_t)(w >> 16);
+            }
+            PHASE_MARK(1);
+        } else {
             // the start points are exactly p0 + k * dlt, k = 1 .. n_lights (closed form)
             f3 o_first, o_last;
             const float margin = screen_segment(true, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
-            RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
             PHASE_MARK(0);
-            const bool screened = margin < 1.0e38f;
-            const GrazeCtx G = graze_ctx(true, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
-            uint32_t *graze_list = L.sample; // (free until the samples are sorted)
-            uint32_t n_graze = 0;
-            n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, screened ? &G : nullptr, graze_list, n_graze);
+#if defined(STEP_STATS)
+            unsigned long long *stats = tot.st;
+#else
+            unsigned long long *stats = nullptr;
+#endif
+            n_cand = screen_sorted_level(fr, L, leaf_prims, count, lane, o_first, o_last, margin, p0, dlt, pixel, leaf, k_off,
+                                         use_sort, stats);
             PHASE_MARK(1);
-            use_sort = n_cand >= SORT_MIN_CAND;
-#ifdef STEP_STATS
-            tot.st[8] += use_sort;
-#endif
-            wave_lds_sync();
-            // (without the sort every candidate is tested in every pass: the marks just go)
-            build_cell_masks(L, fan, leaf_prims, use_sort ? n_cand : 0u, lane, screened ? &G : nullptr, graze_list, n_graze);
-            if (!use_sort)
-                for (uint32_t c = lane; c < n_cand; c += 64) L.cand[c] &= (uint16_t)(CAND_FULL_MASK - 1u);
-            wave_lds_sync();
-#ifdef STEP_STATS
-            tot.st[10] += n_graze;
-            tot.st[11] += n_graze != 0;
-            tot.st[13] += count;
-#endif
-            if (n_graze && graze_resolve(fr, leaf_prims, graze_list, n_graze, p0, dlt, pixel, leaf, k_off, lane)) {
-#ifdef STEP_STATS
-                tot.st[12]++;
-#endif
-                // the float test accepts a pair the screens would drop: this record without screens
-                fan = make_fan(o_first, o_last, fr.light_pos.z, 3.0e38f);
-                wave_lds_sync();
-                n_cand = build_fan_candidates(L, fan, leaf_prims, count, lane, nullptr, graze_list, n_graze);
-                wave_lds_sync();
-                build_cell_masks(L, fan, leaf_prims, n_cand, lane, nullptr, graze_list, n_graze);
-            }
         }
+#ifdef STEP_STATS
+        tot.st[8] += use_sort;
+#endif
         wave_lds_sync();
         PHASE_MARK(2);
 
@@ -507,16 +616,18 @@ template <bool IEEE>
 __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPrim *__restrict__ prims,
                                                     const DMat *__restrict__ mats,
                                                     const DRec *__restrict__ recs, float4 *__restrict__ colors,
-                                                    SortLds &L, uint32_t lane, uint32_t ridx, ShadeTotals &tot) {
+                                                    const CandLists &lists, SortLds &L, uint32_t lane, uint32_t ridx,
+                                                    ShadeTotals &tot) {
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel;
         const DMat mat = mats[rc.mat];
         f3 o, d;
         primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
         uint32_t lit = 0;
-        const float4 sum = shade_level_sorted<IEEE>(fr, prims + rc.first, rc.count, pixel, rc.leaf, mat,
+        const float4 sum = shade_level_sorted<IEEE, true>(fr, prims + rc.first, rc.count, pixel, rc.leaf, mat,
                                                     f3_make(rc.nx, rc.ny, rc.nz), f3_make(rc.px, rc.py, rc.pz),
-                                                    f3_scale(d, -1.f) /* raytracing.h:47 */, 0u, L, lane, tot, lit);
+                                                    f3_scale(d, -1.f) /* raytracing.h:47 */, 0u, L, lane, tot, lit,
+                                                    lists.pool + lists.cand_off[ridx], lists.cand_n[ridx]);
         if (lane == 0) colors[ridx] = sum;
         tot.lit += lit;
 }

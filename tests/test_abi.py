@@ -26,7 +26,7 @@ def test_header_functions_are_exported(rtx):
 def test_struct_sizes_match_the_header(capi):
     assert C.sizeof(capi.Material) == 32 and C.sizeof(capi.Light) == 24
     assert C.sizeof(capi.Prim) == 48 and C.sizeof(capi.Node) == 32 and C.sizeof(capi.Leaf) == 8
-    assert C.sizeof(capi.Hit) == 32 and C.sizeof(capi.Params) == 52 and C.sizeof(capi.Stats) == 72
+    assert C.sizeof(capi.Hit) == 32 and C.sizeof(capi.Params) == 52 and C.sizeof(capi.Stats) == 80
 
 
 def test_defaults_are_the_reference_settings(rtx, capi):

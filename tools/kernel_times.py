@@ -48,10 +48,11 @@ for name in names or ["bunny", "buddha"]:
         t0 = time.perf_counter()
         rgb, st = sc.render(p, timing=True)     # rtx_render: includes the read-back over PCIe
         wall.append((time.perf_counter() - t0) * 1e3)
-        out.append(list(st.kernel_ms))
+        out.append(list(st.kernel_ms) + [st.screen_ms])
     a = np.array(out)
     print("%-13s %dx%d N=%d hits=%d tests=%.3g lit=%d" % (name, w, h, nl, st.hits, st.shadow_tests, st.lit_samples))
     print("   trace ms ", " ".join("%.3f" % x for x in a[:, 0]))
+    print("   screen ms", " ".join("%.3f" % x for x in a[:, 4]))
     print("   shade ms ", " ".join("%.3f" % x for x in a[:, 1]))
     print("   merge ms ", " ".join("%.3f" % x for x in a[:, 2]))
     print("   host wall ms incl. PCIe read-back ", " ".join("%.3f" % x for x in wall))
