@@ -256,18 +256,21 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
  * read back), so it cannot be recorded into a HIP graph: a capturing stream
  * makes the call fail with RTX_ERR_HIP.  Same arguments, same kernels and the
  * same output bytes as rtx_render_device, but every per-frame work buffer
- * (hit records, their colours and work lists, one record head per pixel,
- * tile queues, counters) is carved from a static device array of
+ * (hit records, their colours, work lists and candidate lists, one record
+ * head per pixel, tile queues, counters) is carved from a static device array of
  * RTX_STATIC_SCRATCH_BYTES that each GPU the library runs on holds from the
  * first rtx_scene_create on it until the process ends; the call allocates
  * and frees nothing.  The caller still passes the scene and d_rgb.
  *   Limits: 4 bytes per rendered pixel plus the tile queues come out of the
- * array first and what is left holds the hit records (96 bytes each).  A
- * frame that leaves room for fewer than RTX_STATIC_MIN_RECORDS records, or
- * that produces more hit records than fit (in any of the 8 equal shards of
- * the record array), fails with RTX_ERR_LIMIT and a message; nothing is
- * retried or grown.  As a guide: 3840 x 2160 leaves about 340 000 records,
- * 1920 x 1080 about 610 000.
+ * array first; what is left is split per hit record into 104 bytes for the
+ * record itself and 32 entries (128 bytes) of the pool that holds the
+ * records' candidate lists (a record needs as many entries as its leaf has
+ * primitives; frames with at most 32 light samples keep no lists).  A frame
+ * that leaves room for fewer than RTX_STATIC_MIN_RECORDS records, that
+ * produces more hit records than fit (in any of the 8 equal shards of the
+ * record array), or whose lists need more than the pool holds, fails with
+ * RTX_ERR_LIMIT and a message; nothing is retried or grown.  As a guide:
+ * 3840 x 2160 leaves about 430 000 records, 1920 x 1080 about 540 000.
  *   All calls on one GPU share that GPU's array (whatever the scene or
  * stream): calls that overlap in time on one GPU race and give undefined
  * frames; calls on different GPUs are independent. */

@@ -68,12 +68,14 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                                                               uint32_t *__restrict__ pool, uint32_t pool_cap,
                                                               DCounters *__restrict__ ctr) {
     __shared__ uint32_t graze_lists[SCREEN_BLOCK / 64][SCREEN_GRAZE_LIST];
+    __shared__ uint32_t graze_counts[SCREEN_BLOCK / 64]; // pairs listed for the wave's current record
     const RecMap map = rec_map(ctr, rec_cap); // final: written by the trace kernel
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const float nl = (float)fr.n_lights;
     uint32_t *__restrict__ graze_list = graze_lists[wave];
+    uint32_t *graze_count = &graze_counts[wave];
 #ifdef STEP_STATS
     unsigned long long st_pairs = 0, st_recs = 0, st_open = 0, st_prims = 0;
 #endif
@@ -107,7 +109,9 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
 #endif
         const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
         const GrazeCtx G = graze_ctx(closed, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
-        uint32_t n_cand = 0, n_graze = 0;
+        uint32_t n_cand = 0;
+        if (lane == 0) *graze_count = 0u;
+        wave_lds_sync();
         for (uint32_t base = 0; base < count; base += 64) {
             const uint32_t t = base + lane;
             bool keep = false;
@@ -134,18 +138,23 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                     }
                 }
             }
-            if (screened) graze_push(graze_list, SCREEN_GRAZE_LIST, n_graze, code, t, first, cnt);
+            if (code == 1u) { // the pairs of this lane's triangle, in any order (few lanes have any)
+                const uint32_t pos = atomicAdd(graze_count, cnt);
+                for (uint32_t r = 0; r < cnt; r++)
+                    if (pos + r < SCREEN_GRAZE_LIST) graze_list[pos + r] = t | ((first + r) << 16);
+            }
             const unsigned long long mask = __ballot(keep);
             if (keep)
                 out[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
                     t | (cells << 16);
             n_cand += (uint32_t)__popcll(mask);
         }
+        wave_lds_sync();
+        const uint32_t n_graze = *graze_count;
 #ifdef STEP_STATS
         st_pairs += n_graze, st_recs += n_graze != 0, st_prims += count;
 #endif
         if (n_graze) {
-            wave_lds_sync();
             if (graze_resolve(fr, leaf_prims, graze_list, SCREEN_GRAZE_LIST, n_graze, closed, p0, step, dlt, rc.pixel, rc.leaf,
                               0u, lane)) {
                 // a pair the screens would drop is accepted by the float test: this record without screens

@@ -107,7 +107,7 @@ def test_static_entry_point_limits(op, capi, scenes, rtx):
     b = op.OracleBuilder(10)
     d = scenes.assemble(b, "spheres")           # every pixel hits the walls
     sc = rtx.Scene(d)
-    # 4 bytes per pixel alone exceed the 64 MiB array (refused before anything is written)
+    # 4 bytes per pixel alone fill the 128 MiB array (refused before anything is written)
     p = capi.default_params(8192, 4096, 1, 1)
     out = DeviceBytes(2048 * 1024 * 3, 0)
     with pytest.raises(rtx.RtxError) as e:
@@ -121,6 +121,19 @@ def test_static_entry_point_limits(op, capi, scenes, rtx):
     st = sc.render_device(p, out.ptr.value, 0)
     assert st.hits >= 2048 * 1024
     out.free()
+    # records and pixels fit, the records' candidate lists (one entry per primitive of a record's
+    # leaf, here a whole mesh in a single leaf) do not
+    b0 = op.OracleBuilder(0)
+    sc0 = rtx.Scene(scenes.assemble(b0, "bunny"))
+    p = capi.default_params(640, 360, 40, 1)
+    out = DeviceBytes(640 * 360 * 3, 0)
+    with pytest.raises(rtx.RtxError) as e:
+        sc0.render_device_static(p, out.ptr.value, 0)
+    assert e.value.status == 5 and "candidate lists" in str(e.value)
+    st = sc0.render_device(p, out.ptr.value, 0)
+    assert st.hits > 5000 and st.render_attempts == 2   # (the allocating entry point grows its pool)
+    out.free()
+    sc0.close()
     # a frame that fits still renders after the refusals
     p = capi.default_params(300, 300, 2, 1)
     rgb_a, st_a, rgb_b, st_b = _render_pair(sc, p)
