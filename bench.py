@@ -368,12 +368,13 @@ def main():
     trace_ms = sum(f.kernel_ms[0] for f in frames)
     shade_ms = sum(f.kernel_ms[1] for f in frames)
     merge_ms = sum(f.kernel_ms[2] for f in frames)
+    screen_ms = sum(f.screen_ms for f in frames)
     counts = torch.tensor([elapsed, float(st.primary_rays), float(st.shadow_rays), float(st.shadow_tests),
                            float(st.hits), float(st.lit_samples), float(st.shadow_tests_run)],
                           dtype=torch.float64, device=dev)
     # per rank, for the slowest-rank columns of an N > 1 line
-    per_rank = torch.tensor([trace_ms / args.steps, shade_ms / args.steps, merge_ms / args.steps, gather_ms,
-                             float(st.hits)], dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([trace_ms / args.steps, screen_ms / args.steps, shade_ms / args.steps, merge_ms / args.steps,
+                             gather_ms, float(st.hits)], dtype=torch.float64, device=dev)
     rank_max, rank_min = per_rank.clone(), per_rank.clone()
     if world > 1:
         mx = counts.clone()
@@ -474,7 +475,9 @@ def main():
                         "note": "measured HBM bytes of one launch (rocprofv3 PMC passes, profiles/hbm_traffic.json) "
                                 "/ launch time: the scene is cache resident, HBM is not the bound"},
             },
-            "kernel_ms": {"trace": trace_ms / k, "shade": shade_avg_ms, "merge": merge_ms / k},
+            # trace: tile list, primary rays, work lists; screen: the records' candidate lists
+            # (screen_kernel); shade: the shadow-ray + BSDF kernel the roofline block describes; merge
+            "kernel_ms": {"trace": trace_ms / k, "screen": screen_ms / k, "shade": shade_avg_ms, "merge": merge_ms / k},
             # cold path of this process (rank 0): scene creation and the first frames of a handle
             "cold": {"scene_create_first_ms": create_first_ms, "scene_create_again_ms": create_again_ms,
                      "first_minus_again_ms": create_first_ms - create_again_ms,
@@ -485,7 +488,7 @@ def main():
         if world > 1:
             # slowest and fastest rank, per frame: a poor scaling point shows here whether it is the
             # kernels of the heaviest share, the spread between the shares, or the exchange step
-            names = ("trace_ms", "shade_ms", "merge_ms", "gather_ms", "hit_records")
+            names = ("trace_ms", "screen_ms", "shade_ms", "merge_ms", "gather_ms", "hit_records")
             out["ranks"] = {"max": dict(zip(names, rank_max)), "min": dict(zip(names, rank_min)),
                             "note": "per-frame averages over the timed steps; kernel times are HIP events on the "
                                     "rank's stream (with several frames in flight they include time shared with "

@@ -223,7 +223,9 @@ __device__ __forceinline__ float pyramid_separation(const ShadeLds &L, f3 v0, f3
 // is shaded without screens.  m is half the frame's screen margin: a quarter of that margin
 // is the screens' own rounding (screen_margin()), and the rest covers s' against o - v0.
 #define GRAZE_EPS 6.1e-8f // 2^-24 and room for the higher-order terms
+#ifndef GRAZE_KMAX
 #define GRAZE_KMAX 8u
+#endif
 #define GRAZE_LIST 256u   // pairs per level screened inside the shading kernel (bounce levels); more: no screens
 
 struct GrazeCtx {

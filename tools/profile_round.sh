@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/round
 mkdir -p $O
-W="${@:-buddha bunny dino_spheres multi default}"
+W="${@:-buddha bunny dino_spheres multi default default_500}"
 cd /tmp
 for w in $W; do
     echo "pmc sq $w"
