@@ -296,9 +296,6 @@ __device__ __forceinline__ uint32_t graze_check(const GrazeCtx &g, const DPrim *
 // in the leaf | sample << 16), in lane order.  All lanes of the wave take part.
 __device__ __forceinline__ void graze_push(uint32_t *__restrict__ list, uint32_t cap, uint32_t &n_list, uint32_t code,
                                            uint32_t prim, uint32_t first, uint32_t count) {
-#ifdef GRAZE_SKIP_PUSH
-    return;
-#endif
     const uint32_t mine = (code == 1u) ? count : 0u;
     if (!__any(mine != 0u)) return;
     uint32_t incl = mine;
@@ -321,9 +318,6 @@ __device__ __forceinline__ bool graze_resolve(const DFrame &fr, const DPrim *__r
                                               const uint32_t *__restrict__ list, uint32_t cap, uint32_t n_list,
                                               bool closed, f3 p0, f3 step, f3 dlt, uint32_t pixel, uint32_t leaf,
                                               uint32_t k_off, uint32_t lane) {
-#ifdef GRAZE_SKIP_RESOLVE
-    return false;
-#endif
     if (n_list > cap) return true;
     // Nearly all pairs are cleared by the first part of the argument above alone: acceptance needs
     // |A~| <= A_max = 29 eps sigma a b / m, here with a b <= (ell / 2)^2, m at its smallest (half
