@@ -354,6 +354,11 @@ def main():
     exchange(0)
     fence()
     second_frame_ms = (time.perf_counter() - t0) * 1e3
+    # the other slots' first frames (their replicas allocate their work buffers), one at a time
+    for slot in range(1, n_slots):
+        render(slot)
+        exchange(slot)
+        fence()
 
     run_frames(args.warmup)
     fence()

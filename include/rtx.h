@@ -263,18 +263,20 @@ rtx_status rtx_render_device(rtx_scene *scene, const rtx_params *p, void *d_rgb,
  * and frees nothing.  The caller still passes the scene and d_rgb.
  *   Limits: 4 bytes per rendered pixel plus the tile queues come out of the
  * array first; what is left is split per hit record into 104 bytes for the
- * record itself and 32 entries (128 bytes) of the pool that holds the
+ * record itself and 24 entries (96 bytes) of the pool that holds the
  * records' candidate lists (a record needs as many entries as its leaf has
  * primitives; frames with at most 32 light samples keep no lists).  A frame
  * that leaves room for fewer than RTX_STATIC_MIN_RECORDS records, that
  * produces more hit records than fit (in any of the 8 equal shards of the
  * record array), or whose lists need more than the pool holds, fails with
  * RTX_ERR_LIMIT and a message; nothing is retried or grown.  As a guide:
- * 3840 x 2160 leaves about 430 000 records, 1920 x 1080 about 540 000.
+ * 3840 x 2160 leaves about 165 000 records, 1920 x 1080 about 290 000.  (The
+ * array is part of the library's code object: every process that loads the
+ * library pays for its allocation once per device, about 0.35 ms per MiB.)
  *   All calls on one GPU share that GPU's array (whatever the scene or
  * stream): calls that overlap in time on one GPU race and give undefined
  * frames; calls on different GPUs are independent. */
-#define RTX_STATIC_SCRATCH_BYTES (128u << 20)
+#define RTX_STATIC_SCRATCH_BYTES (64u << 20)
 #define RTX_STATIC_MIN_RECORDS 4096u
 rtx_status rtx_render_device_static(rtx_scene *scene, const rtx_params *p, void *d_rgb,
                                     void *hip_stream, rtx_stats *stats);

@@ -68,7 +68,7 @@ static rtx_status fail(rtx_status s, const std::string &msg) {
 // array's name is only a handle for hipGetSymbolAddress: the address the kernels get is
 // the one resolved per device in scratch_resolve().
 #define STATIC_SCRATCH_BYTES RTX_STATIC_SCRATCH_BYTES
-#define STATIC_POOL_PER_RECORD 32u // entries of the candidate pool per hit record in the static work area
+#define STATIC_POOL_PER_RECORD 24u // entries of the candidate pool per hit record in the static work area
 #define POOL_PER_RECORD 64u        // first guess for the allocated pool
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 
@@ -162,8 +162,8 @@ struct ColdTrace {
 };
 
 // sampled = false: the exhaustive comparisons (some 50 ms).  sampled = true: one bit pattern
-// pair in 64, a sixteenth of the chain cases and of the division operands (under 2 ms); a
-// part whose v_rcp_f32 / v_rsq_f32 differ from gfx950's would fail either.
+// pair in 64, 1/64 of the chain cases and 1/32 of the division operands (about 1 ms of kernel
+// time); a part whose v_rcp_f32 / v_rsq_f32 differ from gfx950's would fail either.
 static rtx_status selftest_run(int device, uint64_t out[7], bool sampled) {
     if (!out) return fail(RTX_ERR_INVALID, "null argument");
     if (device < 0 || device >= rtx_device_count()) return fail(RTX_ERR_NO_DEVICE, "no such HIP device");
@@ -180,11 +180,11 @@ static rtx_status selftest_run(int device, uint64_t out[7], bool sampled) {
         e = hipGetLastError();
         tr.mark("selftest", "first kernel launch");
         if (e == hipSuccess) {
-            selftest_chain_kernel<<<sampled ? 1024 : 16384, 256>>>(d + 3, d + 2, d + 4);
+            selftest_chain_kernel<<<sampled ? 256 : 16384, 256>>>(d + 3, d + 2, d + 4);
             e = hipGetLastError();
         }
         if (e == hipSuccess) {
-            selftest_div_kernel<<<1024, 256>>>(d + 6, d + 5, sampled ? 256u : 4096u);
+            selftest_div_kernel<<<1024, 256>>>(d + 6, d + 5, sampled ? 128u : 4096u);
             e = hipGetLastError();
         }
     }

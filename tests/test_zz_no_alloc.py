@@ -67,7 +67,7 @@ def test_static_entry_point_equals_render_device(op, capi, scenes, rtx):
     # first call: tiles in fixed order (the boxes cover much of a square frame), 150 samples
     # (wave-per-record kernel with sorted samples); second call, smaller: fewer pixels and
     # records than the first left behind in the array, few-samples kernel
-    frames = [(640, 640, 150, 3), (200, 120, 5, 4)]
+    frames = [(512, 512, 150, 3), (200, 120, 5, 4)]
     for w, h, nl, seed in frames:
         p = capi.default_params(w, h, nl, seed)
         rgb_a, st_a, rgb_b, st_b = _render_pair(sc, p)
@@ -107,7 +107,7 @@ def test_static_entry_point_limits(op, capi, scenes, rtx):
     b = op.OracleBuilder(10)
     d = scenes.assemble(b, "spheres")           # every pixel hits the walls
     sc = rtx.Scene(d)
-    # 4 bytes per pixel alone fill the 128 MiB array (refused before anything is written)
+    # 4 bytes per pixel alone exceed the 64 MiB array (refused before anything is written)
     p = capi.default_params(8192, 4096, 1, 1)
     out = DeviceBytes(2048 * 1024 * 3, 0)
     with pytest.raises(rtx.RtxError) as e:
