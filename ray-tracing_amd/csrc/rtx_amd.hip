@@ -508,6 +508,9 @@ static float screen_margin(const rtx_scene *s, const rtx_params *p) {
     double r = std::max<double>(s->coord_max, 750.0);
     r = std::max(r, fabs((double)s->light.position[2]));
     r += fabs((double)p->acne) * ((double)p->n_lights + 1.0);
+    // (the screens take maxima of products of coordinates: beyond this they could overflow, and a
+    // NaN would drop out of a maximum instead of failing a comparison)
+    if (!(r < 1.0e18)) return 3.0e38f;
     const double m = std::max<double>(CULL_MARGIN, r * (1.0 / 262144.0)); // 2^-18
     return (m < 3.0e38) ? (float)m : 3.0e38f;
 }

@@ -10,9 +10,10 @@
 // grazing guard, and the survivors (with their light-cell masks where the record will sort
 // its samples) written to the record's block of the pool.  classify_kernel has given every
 // record a block of as many entries as its leaf has primitives.  The shading kernel then
-// carries no screening code (fewer registers, less scratch), and this kernel runs at full
-// occupancy.  Deeper levels of mirror bounces start from other points and screen for
-// themselves in the bounce build of the shading kernel.
+// carries no screening code (fewer registers, next to no scratch), and this kernel can spend
+// registers freely (it is bound by vector issue at three waves per SIMD).  Deeper levels of
+// mirror bounces start from other points and screen for themselves in the bounce build of
+// the shading kernel.
 
 // Whether a record is shaded with sorted samples: classify_kernel, screen_kernel and the
 // shading kernel must agree.  closed: all three components of the start points have the
