@@ -577,6 +577,73 @@ def test_huge_triangles(op, capi, rtx, scenes):
     sc.close()
 
 
+def _terrain(capi, n, x0, x1, y0, y1, z, noise, seed, material, n_fins):
+    """An n x n grid of vertices over [x0, x1] x [y0, y1] at height z +- noise, as 2 (n-1)^2
+    triangles of generic shape (the vertices are also shifted a little sideways), after n_fins
+    small upright ones."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.linspace(x0, x1, n), np.linspace(y0, y1, n), indexing="ij")
+    cell = (x1 - x0) / (n - 1)
+    v = np.stack([xs + rng.uniform(-0.3, 0.3, xs.shape) * cell, ys + rng.uniform(-0.3, 0.3, xs.shape) * cell,
+                  z + rng.uniform(-1.0, 1.0, xs.shape) * noise], axis=2).astype(np.float32)
+    tris = (capi.Prim * (2 * (n - 1) * (n - 1) + n_fins))()
+    k = 0
+    for _ in range(n_fins):   # small upright triangles standing on the terrain: they cast the shadows
+        cx, cy = rng.uniform(x0 + cell, x1 - cell), rng.uniform(y0 + cell, y1 - cell)
+        ang, half = rng.uniform(0.0, np.pi), rng.uniform(1.0, 4.0)
+        dx, dy = half * np.cos(ang), half * np.sin(ang)
+        tris[k].type = capi.RTX_PRIM_TRIANGLE
+        tris[k].g[0:9] = [cx - dx, cy - dy, z - 0.5, cx + dx, cy + dy, z - 0.5,
+                          cx + rng.uniform(-1, 1), cy + rng.uniform(-1, 1), z + rng.uniform(1.5, 4.0)]
+        tris[k].material = material
+        k += 1
+    for i in range(n - 1):
+        for j in range(n - 1):
+            for a, b, c in (((i, j), (i + 1, j), (i, j + 1)), ((i + 1, j), (i + 1, j + 1), (i, j + 1))):
+                tris[k].type = capi.RTX_PRIM_TRIANGLE
+                tris[k].g[0:9] = [float(x) for q in (a, b, c) for x in v[q]]
+                tris[k].material = material
+                k += 1
+    return tris
+
+
+@pytest.mark.parametrize("noise,light_z,nl,acne", [
+    (0.0, 306.0, 150, 0.01),     # exactly coplanar neighbours, light plane just above the last start point
+    (0.003, 306.0, 300, 0.01),   # planes a few thousandths apart: start points within the guard's bound of many
+    (0.05, 303.0, 100, 0.005),   # samples in index order (one pass), rays within a degree of the terrain
+    (0.4, 320.0, 513, 0.01),
+    (0.02, 301.0, 200, 0.01),    # the start points cross the light plane (no screens for such records)
+])
+def test_grazing_light_over_nearly_flat_terrain(op, capi, rtx, scenes, noise, light_z, nl, acne):
+    """Where the candidate screens' argument is thinnest: shadow rays that run almost inside the
+    planes of many leaf triangles, from start points a few hundredths above those planes (a
+    nearly flat terrain with small upright fins lit from just above it, in one leaf of 490 triangles -
+    sorted samples from 129 on - and one of 1138, more than a candidate list holds).  Every occlusion decision must
+    be the oracle's, with and without the screens."""
+    b = op.OracleBuilder(10)
+    m = b.add_material(scenes.make_material("white"))
+    small = _terrain(capi, 16, 300.0, 480.0, 300.0, 700.0, 300.0, noise, 1, m, 40)
+    large = _terrain(capi, 24, 520.0, 700.0, 300.0, 700.0, 300.0, noise, 2, m, 80)
+    b.add_leaf_box(np.float32((290.0, 290.0, 290.0)), np.float32((490.0, 710.0, 310.0)), small)
+    b.add_leaf_box(np.float32((510.0, 290.0, 290.0)), np.float32((710.0, 710.0, 310.0)), large)
+    d = scenes.assemble(b, dict(boxes=[], light=dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))))
+    sc = rtx.Scene(d)
+    p = capi.default_params(300, 300, nl, 7)
+    p.acne = acne
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    q = capi.Params.from_buffer_copy(p)
+    q.flags |= capi.RTX_FLAG_NO_SCREEN
+    _, st_u = sc.render(q)
+    rgb_c, _, hits_c, st_c = op.render(d, p)
+    sc.close()
+    assert len(hits_c) > 5000 and 0.005 * st_c.shadow_rays < st_c.shadow_rays - st_c.shaded_samples  # real shadows
+    check_hits(hits_g, hits_c, color_tol=5e-3)
+    check_rgb(rgb_g, rgb_c)
+    assert st_g.lit_samples == st_c.shaded_samples == st_u.lit_samples
+    assert st_g.shadow_tests_run <= st_u.shadow_tests_run == st_u.shadow_tests
+
+
 def test_arithmetic_shortcuts_are_exact(rtx):
     """intersect.h:41 `f = 1.f / a`: the kernel's packed reciprocal must return the bits
     of the correctly rounded quotient for every float it is used for (exhaustive).
