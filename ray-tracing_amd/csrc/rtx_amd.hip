@@ -720,6 +720,9 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
     const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
     const uint32_t trace_blocks = (uint32_t)s->n_cu * TRACE_BLOCKS_PER_CU;
+    // screen_kernel: a batch of records per wave when the record buffer were full (the hardware's
+    // block scheduler balances the batches; waves beyond the frame's records leave at once)
+    const uint32_t screen_per_block = SCREEN_BATCH * (SCREEN_BLOCK / 64);
     const uint32_t shade_waves = fr.sort_samples ? SHADE_WAVES_PER_SIMD_SORT : SHADE_WAVES_PER_SIMD;
     uint32_t shade_blocks = (uint32_t)s->n_cu * shade_waves;
     const uint32_t bounce_blocks = (uint32_t)s->n_cu * SHADE_WAVES_PER_SIMD_BOUNCE;
@@ -781,9 +784,16 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
         if (!few)
             classify_kernel<<<few_blocks, 256, 0, st>>>(fr, wb.recs, wb.rec_cap, wb.colors, wb.cand_off, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[4], st));
+#ifdef SCREEN_GRID_RESIDENT
+        const uint32_t screen_blocks = (uint32_t)s->n_cu * SCREEN_GRID_RESIDENT;
+        (void)screen_per_block;
+#else
+        const uint32_t screen_blocks = std::max<uint32_t>(
+            (uint32_t)s->n_cu * SCREEN_WAVES, std::min<uint32_t>((wb.rec_cap + screen_per_block - 1) / screen_per_block, 1u << 18));
+#endif
         if (!few)
-            screen_kernel<<<few_blocks, SCREEN_BLOCK, 0, st>>>(fr, s->d_prims, wb.recs, wb.rec_cap, wb.cand_off, wb.cand_n,
-                                                               wb.pool, wb.pool_cap, wb.ctr);
+            screen_kernel<<<screen_blocks, SCREEN_BLOCK, 0, st>>>(fr, s->d_prims, wb.recs, wb.rec_cap, wb.cand_off, wb.cand_n,
+                                                                  wb.pool, wb.pool_cap, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
         if (few) {
             // few samples: several hit records per wave

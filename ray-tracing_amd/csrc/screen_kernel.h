@@ -5,15 +5,24 @@
 // ---- candidate lists ------------------------------------------------------------------
 // The shading kernel tests a record's shadow rays only against the leaf primitives that
 // survive the record's screens (shade_record.h, shade_sorted.h).  Screening is per record,
-// not per sample, and needs none of the sampling loop's state, so it runs here, one wave per
-// record, lanes over the leaf's primitives: the record's start segment, its screens with the
-// grazing guard, and the survivors (with their light-cell masks where the record will sort
-// its samples) written to the record's block of the pool.  classify_kernel has given every
-// record a block of as many entries as its leaf has primitives.  The shading kernel then
-// carries no screening code (fewer registers, next to no scratch), and this kernel can spend
-// registers freely (it is bound by vector issue at three waves per SIMD).  Deeper levels of
-// mirror bounces start from other points and screen for themselves in the bounce build of
-// the shading kernel.
+// not per sample, and needs none of the sampling loop's state, so it runs here: the record's
+// start segment, its screens with the grazing guard, and the survivors (with their light-cell
+// masks where the record will sort its samples) written to the record's block of the pool.
+// classify_kernel has given every record a block of as many entries as its leaf has
+// primitives.  The shading kernel then carries no screening code (fewer registers, next to no
+// scratch), and this kernel can spend registers freely (it is bound by vector issue at three
+// waves per SIMD).  Deeper levels of mirror bounces start from other points and screen for
+// themselves in the bounce build of the shading kernel.
+//
+// A wave takes SCREEN_BATCH records at a time, in three phases:
+//  1. one lane per record: what depends on the record alone (closed form of the start points,
+//     start segment, ray fan) goes to LDS - the same for all lanes of a wave if it were computed
+//     record by record, two hundred vector instructions each time;
+//  2. record after record, lanes over the leaf's primitives, one pass over the leaf: screens,
+//     guard, survivors to the pool, the guard's (triangle, sample) pairs to one list for the
+//     whole batch;
+//  3. the listed pairs, one per lane whatever record they belong to (a record lists a dozen
+//     on average: checked record by record most lanes would idle), then the list lengths.
 
 // Whether a record is shaded with sorted samples: classify_kernel, screen_kernel and the
 // shading kernel must agree.  closed: all three components of the start points have the
@@ -57,10 +66,67 @@ __device__ __forceinline__ uint32_t graze_quick(const GrazeCtx &g, const DPrim *
 }
 
 #define SCREEN_BLOCK 256
-#define SCREEN_GRAZE_LIST 768u // the guard's (triangle, sample) pairs of one record; more: no screens
-#ifndef SCREEN_WAVES
-#define SCREEN_WAVES 3 // waves per SIMD the kernel is compiled for
+#ifndef SCREEN_BATCH
+#define SCREEN_BATCH 16u // records a wave takes at a time (at most 64: one lane per record in phase 1)
 #endif
+#ifndef SCREEN_GRAZE_LIST
+#define SCREEN_GRAZE_LIST 512u // pairs listed per wave before they must be checked
+#endif
+#define SCREEN_GRAZE_FLUSH (SCREEN_GRAZE_LIST * 5u / 8u) // checked ahead of the next record when more than this many are listed
+#ifndef SCREEN_WAVES
+#define SCREEN_WAVES 5 // waves per SIMD the kernel is compiled for
+#endif
+
+// What phase 1 leaves for a record (LDS, 176 B: a multiple of 16, and lanes r and r + 8 do not
+// meet in a bank).
+#define SCREEN_REC_CLOSED 1u   // start points in closed form
+#define SCREEN_REC_SORTED 2u   // the record sorts its samples: its list carries cell masks
+#define SCREEN_REC_NO_BLOCK 4u // the pool is too small for this frame: no list
+#define SCREEN_REC_OPEN 8u     // shaded without screens (set by phases 2 and 3)
+struct alignas(16) ScreenRec {
+    RayFan fan;
+    float oz_first, oz_last; // (the fan keeps the start points' z times sigma)
+    uint32_t flags;
+    uint32_t count, first, off, ridx; // leaf size, first primitive, block in the pool, record index
+    f3 p0, step, dlt;
+    uint32_t pixel, leaf;
+    uint32_t pad[6];
+};
+static_assert(sizeof(ScreenRec) == 176, "ScreenRec: 44 words");
+
+struct ScreenLds {
+    ScreenRec rec[SCREEN_BATCH];
+    uint32_t pair[SCREEN_GRAZE_LIST]; // primitive offset in the leaf | sample << 16
+    uint8_t slot[SCREEN_GRAZE_LIST];  // the pair's record: index in rec[]
+    uint32_t n_pairs;                 // listed so far (may exceed the list: the excess is not stored)
+    uint32_t pad[3];
+};
+
+// Phase 3: the float test's verdict on pairs [0, n) of the list.  A record one of whose pairs
+// is accepted is marked SCREEN_REC_OPEN.
+__device__ __forceinline__ void screen_resolve(const DFrame &fr, const DPrim *__restrict__ prims, ScreenLds &L, uint32_t n,
+                                               uint32_t lane) {
+    const float per_m = 4.f / fr.cull_margin;
+    for (uint32_t base = 0; base < n; base += 64) {
+        bool open = false;
+        f3 o = fr.light_pos, D = fr.light_pos;
+        const DPrim *__restrict__ p = prims;
+        uint32_t s = 0;
+        if (base + lane < n) {
+            const uint32_t w = L.pair[base + lane], k0 = w >> 16;
+            s = L.slot[base + lane];
+            const ScreenRec &c = L.rec[s];
+            p = prims + c.first + (w & 0xFFFFu);
+            open = graze_pair_open(fr, per_m, p, (c.flags & SCREEN_REC_CLOSED) != 0u, c.p0, c.step, c.dlt, c.pixel, c.leaf, k0,
+                                   k0, o, D);
+        }
+        if (__any(open)) {
+            if (open && graze_pair_hit(p, o, D)) atomicOr(&L.rec[s].flags, SCREEN_REC_OPEN);
+        }
+    }
+    wave_lds_sync();
+}
+
 __global__ __launch_bounds__(SCREEN_BLOCK) __attribute__((amdgpu_waves_per_eu(SCREEN_WAVES, SCREEN_WAVES)))
 void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                                                               const DRec *__restrict__ recs, uint32_t rec_cap,
@@ -68,106 +134,164 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                                                               uint32_t *__restrict__ cand_n,
                                                               uint32_t *__restrict__ pool, uint32_t pool_cap,
                                                               DCounters *__restrict__ ctr) {
-    __shared__ uint32_t graze_lists[SCREEN_BLOCK / 64][SCREEN_GRAZE_LIST];
-    __shared__ uint32_t graze_counts[SCREEN_BLOCK / 64]; // pairs listed for the wave's current record
+    __shared__ ScreenLds lds[SCREEN_BLOCK / 64];
     const RecMap map = rec_map(ctr, rec_cap); // final: written by the trace kernel
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const float nl = (float)fr.n_lights;
-    uint32_t *__restrict__ graze_list = graze_lists[wave];
-    uint32_t *graze_count = &graze_counts[wave];
+    ScreenLds &L = lds[threadIdx.x >> 6];
 #ifdef STEP_STATS
     unsigned long long st_pairs = 0, st_recs = 0, st_open = 0, st_prims = 0;
 #endif
-    for (uint32_t flat = wave_id; flat < map.total; flat += n_waves) {
-        const uint32_t ridx = rec_index(map, flat);
-        const DRec rc = recs[ridx];
-        const uint32_t count = rc.count, off = cand_off[ridx];
-        if ((unsigned long long)off + count > pool_cap) {
-            // the pool is too small for this frame: the host sees the total, grows the pool and
-            // renders the frame again; until then the record has no list
-            if (lane == 0) cand_n[ridx] = 0u;
-            continue;
+    // Batch b takes records b, b + n_batches, b + 2 n_batches, ...: neighbouring records hit the
+    // same leaves, and a batch of 32 records of the densest leaf would last as long as the rest of
+    // the kernel (measured: 0.58 ms against 0.46 on the 4K buddha frame).
+    const uint32_t n_batches = (map.total + SCREEN_BATCH - 1u) / SCREEN_BATCH;
+    for (uint32_t batch = wave_id; batch < n_batches; batch += n_waves) {
+        const uint32_t nb = min(SCREEN_BATCH, (map.total - batch + n_batches - 1u) / n_batches);
+        // ---- phase 1: a record per lane ----
+        if (lane < nb) {
+            ScreenRec c;
+            c.ridx = rec_index(map, lane * n_batches + batch);
+            const DRec rc = recs[c.ridx];
+            c.count = rc.count, c.first = rc.first, c.pixel = rc.pixel, c.leaf = rc.leaf;
+            c.off = cand_off[c.ridx];
+            c.p0 = f3_make(rc.px, rc.py, rc.pz);
+            c.step = f3_scale(f3_make(rc.nx, rc.ny, rc.nz), fr.acne); // raytracing.h:40
+            c.dlt = f3_make(0.f, 0.f, 0.f);
+            const bool cx = acne_chain_delta(c.p0.x, c.step.x, fr.n_lights, c.dlt.x);
+            const bool cy = acne_chain_delta(c.p0.y, c.step.y, fr.n_lights, c.dlt.y);
+            const bool cz = acne_chain_delta(c.p0.z, c.step.z, fr.n_lights, c.dlt.z);
+            const bool closed = cx && cy && cz;
+            f3 o_first, o_last;
+            const float margin = screen_segment(closed, c.p0, c.step, c.dlt, nl, fr.cull_margin, o_first, o_last);
+            c.fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
+            c.oz_first = o_first.z, c.oz_last = o_last.z;
+            // (a block beyond the pool: the host sees the total, grows the pool and renders the
+            // frame again; until then the record has no list)
+            c.flags = (closed ? SCREEN_REC_CLOSED : 0u) | (record_sorts(fr, c.count, closed) ? SCREEN_REC_SORTED : 0u) |
+                      (((unsigned long long)c.off + c.count > pool_cap) ? SCREEN_REC_NO_BLOCK : 0u);
+            L.rec[lane] = c;
         }
-        const DPrim *__restrict__ leaf_prims = prims + rc.first;
-        const f3 nrm = f3_make(rc.nx, rc.ny, rc.nz), p0 = f3_make(rc.px, rc.py, rc.pz);
-        const f3 step = f3_scale(nrm, fr.acne); // raytracing.h:40
-        f3 dlt = f3_make(0.f, 0.f, 0.f);
-        const bool closed = acne_chain_delta3(lane, p0, step, fr.n_lights, dlt);
-        f3 o_first, o_last;
-        const float margin = screen_segment(closed, p0, step, dlt, nl, fr.cull_margin, o_first, o_last);
-        const bool sorted = record_sorts(fr, count, closed);
-        uint32_t *__restrict__ out = pool + off;
-        // One pass over the leaf, a primitive per lane: how far outside the rays' pyramid it lies
-        // (fan_separation; records with samples in index order use the same planes), for a record
-        // that sorts its samples the light cells it can be hit from, the grazing guard for what is
-        // dropped or left out of cells, and the survivors appended to the record's block.
-#ifdef NO_GRAZE
-        const bool screened = false; // (measurement build only: the screens without their guard)
-#else
-        const bool screened = margin < 1.0e38f;
-#endif
-        const RayFan fan = make_fan(o_first, o_last, fr.light_pos.z, margin);
-        const GrazeCtx G = graze_ctx(closed, o_first, o_last, fr.n_lights, fr.cull_margin, margin);
-        uint32_t n_cand = 0;
-        if (lane == 0) *graze_count = 0u;
+        if (lane == 0) L.n_pairs = 0u;
         wave_lds_sync();
-        for (uint32_t base = 0; base < count; base += 64) {
-            const uint32_t t = base + lane;
-            bool keep = false;
-            uint32_t cells = 0xFFFFu, code = 0, first = 0, cnt = 0;
-            if (t < count) {
-                const DPrim *__restrict__ p = leaf_prims + t;
-                keep = true;
-                if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                    float sep;
-                    if (sorted) {
-                        fan_screen(fan, p->a, p->b, p->c, sep, cells);
-                    } else {
-                        sep = fan_separation(fan, p->a, p->b, p->c);
-                    }
-                    keep = !(sep > fan.margin);
-                    if (!keep) cells = 0xFFFFu; // (dropped altogether: the guard looks at it once)
-                    if (screened && (!keep || cells != 0xFFFFu)) {
-                        // (left out of a cell: by the margin at least)
-                        code = graze_quick(G, p, keep ? fan.margin : sep, first, cnt);
-                        if (code == 2u) {
-                            keep = true;
-                            cells = 0xFFFFu;
+        // ---- phase 2: record after record, a primitive per lane ----
+        uint32_t my_n_cand = 0; // lane r: entries of record r's list
+        uint32_t n_listed = 0;  // pairs of the records so far
+        for (uint32_t r = 0; r < nb; r++) {
+            const ScreenRec c = L.rec[r];
+            if (c.flags & SCREEN_REC_NO_BLOCK) continue;
+            const bool closed = (c.flags & SCREEN_REC_CLOSED) != 0u, sorted = (c.flags & SCREEN_REC_SORTED) != 0u;
+            const DPrim *__restrict__ leaf_prims = prims + c.first;
+            uint32_t *__restrict__ out = pool + c.off;
+#ifdef NO_GRAZE
+            const bool screened = false; // (measurement build only: the screens without their guard)
+#else
+            const bool screened = c.fan.margin < 1.0e38f;
+#endif
+            const GrazeCtx G = graze_ctx(closed, f3_make(c.fan.ox[0], c.fan.oy[0], c.oz_first),
+                                         f3_make(c.fan.ox[1], c.fan.oy[1], c.oz_last), fr.n_lights, fr.cull_margin, c.fan.margin);
+            if (n_listed > SCREEN_GRAZE_FLUSH) { // room for this record's pairs
+                screen_resolve(fr, prims, L, n_listed, lane);
+                if (lane == 0) L.n_pairs = 0u;
+                n_listed = 0;
+                wave_lds_sync();
+            }
+            uint32_t n_cand;
+            for (;;) {
+                // One pass over the leaf: how far outside the rays' pyramid a primitive lies
+                // (fan_separation; records with samples in index order use the same planes), for a
+                // record that sorts its samples the light cells it can be hit from, the grazing guard
+                // for what is dropped or left out of cells, and the survivors appended to the block.
+                n_cand = 0;
+                for (uint32_t base = 0; base < c.count; base += 64) {
+                    const uint32_t t = base + lane;
+                    bool keep = false;
+                    uint32_t cells = 0xFFFFu, code = 0, first = 0, cnt = 0;
+                    if (t < c.count) {
+                        const DPrim *__restrict__ p = leaf_prims + t;
+                        keep = true;
+                        if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                            float sep;
+                            if (sorted) {
+                                fan_screen(c.fan, p->a, p->b, p->c, sep, cells);
+                            } else {
+                                sep = fan_separation(c.fan, p->a, p->b, p->c);
+                            }
+                            keep = !(sep > c.fan.margin);
+                            if (!keep) cells = 0xFFFFu; // (dropped altogether: the guard looks at it once)
+                            if (screened && (!keep || cells != 0xFFFFu)) {
+                                // (left out of a cell: by the margin at least)
+                                code = graze_quick(G, p, keep ? c.fan.margin : sep, first, cnt);
+                                if (code == 2u) {
+                                    keep = true;
+                                    cells = 0xFFFFu;
+                                }
+                            }
                         }
                     }
+                    if (code == 1u) { // the pairs of this lane's triangle, in any order (few lanes have any)
+                        const uint32_t pos = atomicAdd(&L.n_pairs, cnt);
+                        for (uint32_t q = 0; q < cnt; q++)
+                            if (pos + q < SCREEN_GRAZE_LIST) {
+                                L.pair[pos + q] = t | ((first + q) << 16);
+                                L.slot[pos + q] = (uint8_t)r;
+                            }
+                    }
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep)
+                        out[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
+                            t | (cells << 16);
+                    n_cand += (uint32_t)__popcll(mask);
                 }
-            }
-            if (code == 1u) { // the pairs of this lane's triangle, in any order (few lanes have any)
-                const uint32_t pos = atomicAdd(graze_count, cnt);
-                for (uint32_t r = 0; r < cnt; r++)
-                    if (pos + r < SCREEN_GRAZE_LIST) graze_list[pos + r] = t | ((first + r) << 16);
-            }
-            const unsigned long long mask = __ballot(keep);
-            if (keep)
-                out[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
-                    t | (cells << 16);
-            n_cand += (uint32_t)__popcll(mask);
-        }
-        wave_lds_sync();
-        const uint32_t n_graze = *graze_count;
+                wave_lds_sync();
+                const uint32_t total = L.n_pairs;
+                if (total <= SCREEN_GRAZE_LIST) {
 #ifdef STEP_STATS
-        st_pairs += n_graze, st_recs += n_graze != 0, st_prims += count;
+                    st_pairs += total - n_listed, st_recs += total != n_listed;
 #endif
-        if (n_graze) {
-            if (graze_resolve(fr, leaf_prims, graze_list, SCREEN_GRAZE_LIST, n_graze, closed, p0, step, dlt, rc.pixel, rc.leaf,
-                              0u, lane)) {
-                // a pair the screens would drop is accepted by the float test: this record without screens
-                for (uint32_t t = lane; t < count; t += 64) out[t] = t | 0xFFFF0000u;
-                n_cand = count;
-#ifdef STEP_STATS
-                st_open++;
-#endif
+                    n_listed = total;
+                    break;
+                }
+                // The list is full.  Pairs of earlier records: check them and run this record again
+                // on the empty list; a record that overflows the list by itself goes without screens.
+                if (n_listed) screen_resolve(fr, prims, L, n_listed, lane);
+                if (lane == 0) {
+                    L.n_pairs = 0u;
+                    if (!n_listed) L.rec[r].flags = c.flags | SCREEN_REC_OPEN;
+                }
+                wave_lds_sync();
+                if (!n_listed) break;
+                n_listed = 0;
             }
-            wave_lds_sync();
+            if (lane == r) my_n_cand = n_cand;
+#ifdef STEP_STATS
+            st_prims += c.count;
+#endif
         }
-        if (lane == 0) cand_n[ridx] = n_cand | ((sorted && n_cand >= SORT_MIN_CAND) ? CAND_N_SORT : 0u);
+        // ---- phase 3: the listed pairs, then every record's list length ----
+        if (n_listed) screen_resolve(fr, prims, L, n_listed, lane);
+        uint32_t my_flags = 0, my_count = 0, my_ridx = 0;
+        if (lane < nb) my_flags = L.rec[lane].flags, my_count = L.rec[lane].count, my_ridx = L.rec[lane].ridx;
+        // a pair the screens would drop is accepted by the float test: that record without screens
+        unsigned long long open = __ballot((my_flags & SCREEN_REC_OPEN) != 0u);
+#ifdef STEP_STATS
+        st_open += (unsigned long long)__popcll(open);
+#endif
+        while (open) {
+            const uint32_t r = (uint32_t)__builtin_ctzll(open);
+            open &= open - 1ull;
+            uint32_t *__restrict__ out = pool + L.rec[r].off;
+            const uint32_t count = L.rec[r].count;
+            for (uint32_t t = lane; t < count; t += 64) out[t] = t | 0xFFFF0000u;
+        }
+        if (lane < nb) {
+            uint32_t n = (my_flags & SCREEN_REC_OPEN) ? my_count : my_n_cand;
+            if (my_flags & SCREEN_REC_NO_BLOCK) n = 0u;
+            cand_n[my_ridx] = n | (((my_flags & SCREEN_REC_SORTED) && n >= SORT_MIN_CAND) ? CAND_N_SORT : 0u);
+        }
+        wave_lds_sync(); // rec[] is rewritten by the next batch
     }
 #ifdef STEP_STATS
     if (lane == 0) {

@@ -310,20 +310,48 @@ __device__ __forceinline__ void graze_push(uint32_t *__restrict__ list, uint32_t
     n_list += __shfl(incl, 63);
 }
 
-// The float test itself on the listed pairs, one per lane, exactly as the sample loop runs it
-// (same start point - the closed form, or the running sum of raytracing.h:40 step by step -
-// same light sample, same direction).  True if any pair is accepted, or the list overflowed:
-// the record is then shaded without screens (a few dozen records of a 4K frame).
+// One listed pair (triangle p, sample k0 of a record): the sample's start point o and its
+// un-normalised direction D exactly as the sample loop has them (the closed form, or the running
+// sum of raytracing.h:40 step by step; light sample k_idx of the record's sequence).  Nearly all
+// pairs are cleared by the first part of the argument above alone: acceptance needs
+// |A~| <= A_max = 29 eps sigma a b / m, here with a b <= (ell / 2)^2, m at its smallest (half
+// the screen margin, and half of that as in graze_check; per_m = 4 / margin) and 7 eps a b for
+// A~ against the value computed here, tested on the direction before it is normalised:
+// |e1 . (D x e2)| > A_max |D|.  Returns false for a pair cleared that way; the others must go
+// through the float test (graze_pair_hit).
+__device__ __forceinline__ bool graze_pair_open(const DFrame &fr, float per_m, const DPrim *__restrict__ p, bool closed,
+                                                f3 p0, f3 step, f3 dlt, uint32_t pixel, uint32_t leaf, uint32_t k0,
+                                                uint32_t k_idx, f3 &o, f3 &D) {
+    o = p0;
+    if (closed) {
+        const float s = (float)(k0 + 1u);
+        o = f3_make(p0.x + s * dlt.x, p0.y + s * dlt.y, p0.z + s * dlt.z);
+    } else {
+        for (uint32_t k = 0; k <= k0; k++) o = f3_add(o, step);
+    }
+    f3 l = fr.light_pos;
+    light_sample(fr.seed, pixel, leaf, k_idx, l.x, l.y);
+    D = f3_sub(l, o);
+    const f3 sv = f3_sub(o, p->a);
+    const float A = f3_dot(p->b, f3_cross(D, p->c));
+    const float sig = __builtin_amdgcn_sqrtf(f3_dot(sv, sv)) * 1.001f, ab = 0.25f * p->ell * p->ell;
+    const float a_max = GRAZE_EPS * ab * (29.f * sig * per_m + 7.f) * 1.05f;
+    return !(A * A > a_max * a_max * f3_dot(D, D) * 1.001f); // (a NaN leaves the pair open)
+}
+__device__ __forceinline__ bool graze_pair_hit(const DPrim *__restrict__ p, f3 o, f3 D) {
+    const f3 d = f3_normalize(D); // raytracing.h:43
+    float t;
+    return tri_hit(o, d, p->a, p->b, p->c, t);
+}
+
+// The float test itself on the listed pairs of one record, one per lane.  True if any pair is
+// accepted, or the list overflowed: the record is then shaded without screens (a few dozen
+// records of a 4K frame).
 __device__ __forceinline__ bool graze_resolve(const DFrame &fr, const DPrim *__restrict__ leaf_prims,
                                               const uint32_t *__restrict__ list, uint32_t cap, uint32_t n_list,
                                               bool closed, f3 p0, f3 step, f3 dlt, uint32_t pixel, uint32_t leaf,
                                               uint32_t k_off, uint32_t lane) {
     if (n_list > cap) return true;
-    // Nearly all pairs are cleared by the first part of the argument above alone: acceptance needs
-    // |A~| <= A_max = 29 eps sigma a b / m, here with a b <= (ell / 2)^2, m at its smallest (half
-    // the screen margin, and half of that as in graze_check) and 7 eps a b for A~ against the value
-    // computed here, tested on the direction before it is normalised: |e1 . (D x e2)| > A_max |D|.
-    // Only a pair that is not cleared that way goes through the float test.
     const float per_m = 4.f / fr.cull_margin;
     for (uint32_t base = 0; base < n_list; base += 64) {
         bool open = false;
@@ -332,28 +360,10 @@ __device__ __forceinline__ bool graze_resolve(const DFrame &fr, const DPrim *__r
         if (base + lane < n_list) {
             const uint32_t w = list[base + lane], k0 = w >> 16;
             p = leaf_prims + (w & 0xFFFFu);
-            if (closed) {
-                const float s = (float)(k0 + 1u);
-                o = f3_make(p0.x + s * dlt.x, p0.y + s * dlt.y, p0.z + s * dlt.z);
-            } else {
-                for (uint32_t k = 0; k <= k0; k++) o = f3_add(o, step);
-            }
-            f3 l = fr.light_pos;
-            light_sample(fr.seed, pixel, leaf, k_off + k0, l.x, l.y);
-            D = f3_sub(l, o);
-            const f3 sv = f3_sub(o, p->a);
-            const float A = f3_dot(p->b, f3_cross(D, p->c));
-            const float sig = __builtin_amdgcn_sqrtf(f3_dot(sv, sv)) * 1.001f, ab = 0.25f * p->ell * p->ell;
-            const float a_max = GRAZE_EPS * ab * (29.f * sig * per_m + 7.f) * 1.05f;
-            open = !(A * A > a_max * a_max * f3_dot(D, D) * 1.001f); // (a NaN leaves the pair open)
+            open = graze_pair_open(fr, per_m, p, closed, p0, step, dlt, pixel, leaf, k0, k_off + k0, o, D);
         }
         if (__any(open)) {
-            bool accepted = false;
-            if (open) {
-                const f3 d = f3_normalize(D); // raytracing.h:43
-                float t;
-                accepted = tri_hit(o, d, p->a, p->b, p->c, t);
-            }
+            const bool accepted = open && graze_pair_hit(p, o, D);
             if (__any(accepted)) return true;
         }
     }
