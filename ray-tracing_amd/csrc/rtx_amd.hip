@@ -7,8 +7,9 @@
 //                    leaf (raytracing.h:74-98, :29-34; intersect.h) -> hit records
 //   classify_kernel  one lane per hit record: the record goes to the work list of its
 //                    class (how it will be shaded, how heavy its leaf is)
-//   screen_kernel    one wave per hit record, lanes over its leaf: the primitives the
-//                    record's shadow rays can reach at all -> one candidate list per record
+//   screen_kernel    sixteen hit records per wave, each with lanes over its leaf: the
+//                    primitives the record's shadow rays can reach at all -> one
+//                    candidate list per record
 //   shade_kernel     one wave per hit record, lanes over the light samples: shadow
 //                    rays against the record's leaf + BSDF (raytracing.h:36-50,
 //                    shade.h) -> one colour per record   (shade_few_kernel: several
