@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""One case of tools/gpu_stress.py by its parameters (GPU box), with the default build of the
+BSDF and with RTX_FLAG_IEEE_SHADE: which part of a colour difference is the fast BSDF.
+
+    python tools/gpu_case.py <scene> <depth> <light_z> <acne> <n_lights> <w> <h> <bounces> <cam_x> <cam_y> <cam_z> <seed>
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_py as op  # noqa: E402
+
+capi = op.capi
+rtx = importlib.import_module("ray-tracing_amd")
+scenes = importlib.import_module("ray-tracing_amd.scenes")
+
+name, depth, light_z, acne, nl, w, h, bounces = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]), \
+    int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+camera = tuple(float(x) for x in sys.argv[9:12])
+seed = int(sys.argv[12])
+cfg = dict(scenes.CONFIGS[name])
+cfg["light"] = dict(position=(250.0, 250.0, light_z), color=(255.0, 255.0, 255.0))
+builder = op.OracleBuilder(depth)  # (owns the arrays the description points into)
+d = scenes.assemble(builder, cfg)
+for label, flags in (("fast BSDF", 0), ("IEEE BSDF", capi.RTX_FLAG_IEEE_SHADE)):
+    p = capi.default_params(w, h, nl, seed)
+    p.acne, p.max_depth, p.flags = acne, bounces, flags
+    p.camera[:] = camera
+    q = capi.Params.from_buffer_copy(p)
+    if nl < 129:
+        q.flags |= op.ORC_FLAG_WAVE_SUM  # the oracle adds a record's samples in the GPU's order
+    rgb_c, _, hits_c, st_c = op.render(d, q)
+    sc = rtx.Scene(d)
+    rgb_g, hits_g = sc.render_hits(p)
+    _, st_g = sc.render(p)
+    sc.close()
+    same = len(hits_g) == len(hits_c) and all(np.array_equal(hits_g[k], hits_c[k]) for k in ("pixel", "ordinal", "leaf", "prim"))
+    rel = -1.0
+    if same and len(hits_c):
+        rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
+        err = np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-2 + 1e-3 * rec_max)
+        rel = float(err.max())
+        worst = np.unravel_index(int(err.argmax()), err.shape)
+        print("   worst record %d channel %d: gpu %r oracle %r" % (worst[0], worst[1], hits_g["color"][worst[0]], hits_c["color"][worst[0]]))
+    print("%s: hits %d ids %s lit %d vs %d rgb equal %.5f rel %.2e" %
+          (label, len(hits_c), same, st_g.lit_samples, st_c.shaded_samples,
+           float((rgb_g == rgb_c).all(axis=2).mean()), rel))

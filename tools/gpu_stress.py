@@ -14,7 +14,10 @@ RTX_FLAG_NO_SORT) the oracle adds them in the GPU's order (ORC_FLAG_WAVE_SUM) an
 bound is 5e-4: what is left is the fast build of the BSDF.  With sorted samples the order
 differs, and with the light inside the scene or a negative acne offset contributions of both
 signs cancel in a record's sum, so the order shows (a channel of 0.005 beside one of 135 came
-out 3e-4 apart): 5e-3.
+out 3e-4 apart): 5e-3.  The same cancellation amplifies the fast BSDF's own 4e-5 per sample
+where the order is fixed (light at z = 30, two mirror bounces, 17 samples: a channel of -0.635
+beside one of -9.8 came out 6.9e-4 apart, and 1.9e-7 with RTX_FLAG_IEEE_SHADE -
+tools/gpu_case.py runs one case with both builds): 5e-3 there too unless the case runs the IEEE build.
 
 One case in five draws from the corners the exactness arguments are weakest in: thousands
 of samples (the running acne offset leaves the straight line by many ulps), a mesh scaled
@@ -125,7 +128,8 @@ for case in range(n_cases):
         # noise of the record's large channels: measure it against those as well
         rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
         rel = float((np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-2 + 1e-3 * rec_max)).max())
-    ok = ok_ids and ok_t and ok_lit and ok_screen and within >= 0.999 and rel < (5e-4 if in_order else 5e-3)
+    cancels = (light_z <= 150.0 or acne < 0.0) and not (flags & capi.RTX_FLAG_IEEE_SHADE)
+    ok = ok_ids and ok_t and ok_lit and ok_screen and within >= 0.999 and rel < (5e-4 if in_order and not cancels else 5e-3)
     bad += not ok
     print("%s case %2d corner %d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s screens %s "
           "(%d vs %d) part %d/%d cam %s rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
