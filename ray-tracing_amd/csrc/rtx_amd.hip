@@ -719,7 +719,10 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     uint8_t *d_traced = queued ? reinterpret_cast<uint8_t *>(wb.tiles + (uint64_t)tile_seg * TILE_QUEUES) : nullptr;
     // the queue-driven shading kernels get exactly the waves that are resident at once
     // (a block is one wave per SIMD); the few-samples kernel strides over the records
-    const uint32_t few_blocks = (uint32_t)s->n_cu * 8;
+#ifndef FEW_BLOCKS_PER_CU
+#define FEW_BLOCKS_PER_CU 8
+#endif
+    const uint32_t few_blocks = (uint32_t)s->n_cu * FEW_BLOCKS_PER_CU;
     const uint32_t trace_blocks = (uint32_t)s->n_cu * TRACE_BLOCKS_PER_CU;
     // screen_kernel: a batch of records per wave when the record buffer were full (the hardware's
     // block scheduler balances the batches; waves beyond the frame's records leave at once)
@@ -897,10 +900,16 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
     if (stats) {
         stats->primary_rays = npix;
         stats->hits = n_hits;
-        stats->shadow_rays = (n_hits + s->h_ctr->bounce_hits) * p->n_lights;
-        stats->shadow_tests = ((uint64_t)s->h_ctr->leaf_prims + s->h_ctr->bounce_prims) * p->n_lights;
-        stats->lit_samples = s->h_ctr->lit;
-        stats->shadow_tests_run = s->h_ctr->tests_run;
+        uint64_t leaf_prims = 0, lit = 0, tests_run = 0, bounce_hits = 0, bounce_prims = 0;
+        for (uint32_t k = 0; k < STAT_SHARDS; k++) {
+            leaf_prims += s->h_ctr->stat[k].leaf_prims, lit += s->h_ctr->stat[k].lit;
+            tests_run += s->h_ctr->stat[k].tests_run, bounce_hits += s->h_ctr->stat[k].bounce_hits;
+            bounce_prims += s->h_ctr->stat[k].bounce_prims;
+        }
+        stats->shadow_rays = (n_hits + bounce_hits) * p->n_lights;
+        stats->shadow_tests = (leaf_prims + bounce_prims) * p->n_lights;
+        stats->lit_samples = lit;
+        stats->shadow_tests_run = tests_run;
         stats->render_attempts = attempts;
         stats->record_capacity = wb.rec_cap;
         if (timing) {

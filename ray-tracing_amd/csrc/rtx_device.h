@@ -122,15 +122,24 @@ struct DTileRects {
 #ifndef QUEUE_HEADS
 #define QUEUE_HEADS 64u // queue heads per work list (a power of two, at most 64: one per lane)
 #endif
+#define STAT_SHARDS 32u // copies of the frame's statistics (a power of two)
 struct DCounters {
     uint32_t cand_total; // entries of the candidate pool handed out to the records (classify_kernel)
-    uint32_t pad0;
-    unsigned long long leaf_prims; // sum of the leaf sizes over all records
-    unsigned long long lit;        // light samples that were not occluded
-    unsigned long long tests_run;  // shadow-ray primitive tests executed
-    unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
-    unsigned long long bounce_prims; // sum of the leaf sizes over those
+    uint32_t pad0[11];
     uint32_t pad1[52]; // (the measurement builds keep their statistics here)
+    // Statistics of the frame, added up by every wave when it ends.  Atomics on one address
+    // complete one after the other, about 80 million a second on this chip, whether anyone waits
+    // for the result or not: two per wave on one line cost a kernel of 8192 short waves 0.14 ms
+    // (more than the rest of it).  Hence STAT_SHARDS copies on lines of their own, picked by
+    // block number; the host adds them up.
+    struct {
+        unsigned long long leaf_prims;   // sum of the leaf sizes over all records
+        unsigned long long lit;          // light samples that were not occluded
+        unsigned long long tests_run;    // shadow-ray primitive tests executed
+        unsigned long long bounce_hits;  // mirror rays that hit something in their leaf
+        unsigned long long bounce_prims; // sum of the leaf sizes over those
+        uint32_t pad[22];
+    } stat[STAT_SHARDS];
     // Hit records appended per shard of the record array (may exceed the shard's capacity).
     // The trace kernel appends with one returning atomic per wave and leaf; on one word
     // those would complete at ~50 M/s chip-wide and pace the kernel, so the array is cut

@@ -176,8 +176,9 @@ void shade_kernel(
                                             lds[wave].sorted, levels[BOUNCE ? wave : 0], lane, tot);
         }
     }
-    if (lane == 0 && tot.lit) atomicAdd(&ctr->lit, (unsigned long long)tot.lit);
-    if (lane == 0 && tot.tests) atomicAdd(&ctr->tests_run, tot.tests);
+    auto &stat = ctr->stat[blockIdx.x & (STAT_SHARDS - 1u)];
+    if (lane == 0 && tot.lit) atomicAdd(&stat.lit, (unsigned long long)tot.lit);
+    if (lane == 0 && tot.tests) atomicAdd(&stat.tests_run, tot.tests);
 #if defined(STEP_STATS) || defined(PHASE_TIMES)
     if (lane == 0) {
         unsigned long long *out = reinterpret_cast<unsigned long long *>(ctr->pad1);
@@ -190,8 +191,8 @@ void shade_kernel(
     }
 #endif
     if (lane == 0 && tot.bounce_hits) {
-        atomicAdd(&ctr->bounce_hits, (unsigned long long)tot.bounce_hits);
-        atomicAdd(&ctr->bounce_prims, tot.bounce_prims);
+        atomicAdd(&stat.bounce_hits, (unsigned long long)tot.bounce_hits);
+        atomicAdd(&stat.bounce_prims, tot.bounce_prims);
     }
 }
 
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void shade_few_kernel(
     // statistics: one atomic per wave
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tests_total += __shfl_xor(tests_total, off);
-    if (lane == 0 && lit_total) atomicAdd(&ctr->lit, (unsigned long long)lit_total);
-    if (lane == 0 && tests_total) atomicAdd(&ctr->tests_run, tests_total);
+    auto &stat = ctr->stat[blockIdx.x & (STAT_SHARDS - 1u)];
+    if (lane == 0 && lit_total) atomicAdd(&stat.lit, (unsigned long long)lit_total);
+    if (lane == 0 && tests_total) atomicAdd(&stat.tests_run, tests_total);
 }

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(
     }
     if (valid && slice == 0) first_rec[local] = head;
     } // tiles
-    if (lane == 0 && leaf_prims) atomicAdd(&ctr->leaf_prims, leaf_prims);
+    if (lane == 0 && leaf_prims) atomicAdd(&ctr->stat[blockIdx.x & (STAT_SHARDS - 1u)].leaf_prims, leaf_prims);
 }
 
 // First pass of a frame when the tiles are queued: one lane per tile part (one wave's
