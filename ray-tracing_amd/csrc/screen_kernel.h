@@ -18,9 +18,9 @@
 //  1. one lane per record: what depends on the record alone (closed form of the start points,
 //     start segment, ray fan) goes to LDS - the same for all lanes of a wave if it were computed
 //     record by record, two hundred vector instructions each time;
-//  2. record after record, lanes over the leaf's primitives, one pass over the leaf: screens,
-//     guard, survivors to the pool, the guard's (triangle, sample) pairs to one list for the
-//     whole batch;
+//  2. the leaves of the batch as one stream of primitives, a primitive per lane whatever record
+//     it belongs to: screens, guard, survivors to their record's block of the pool, the guard's
+//     (triangle, sample) pairs to one list for the whole batch;
 //  3. the listed pairs, one per lane whatever record they belong to (a record lists a dozen
 //     on average: checked record by record most lanes would idle), then the list lengths.
 
@@ -70,9 +70,9 @@ __device__ __forceinline__ uint32_t graze_quick(const GrazeCtx &g, const DPrim *
 #define SCREEN_BATCH 16u // records a wave takes at a time (at most 64: one lane per record in phase 1)
 #endif
 #ifndef SCREEN_GRAZE_LIST
-#define SCREEN_GRAZE_LIST 512u // pairs listed per wave before they must be checked
+#define SCREEN_GRAZE_LIST 768u // pairs a wave can list before they are checked (a step lists up to 64 * GRAZE_KMAX)
 #endif
-#define SCREEN_GRAZE_FLUSH (SCREEN_GRAZE_LIST * 5u / 8u) // checked ahead of the next record when more than this many are listed
+static_assert(SCREEN_GRAZE_LIST > 64u * GRAZE_KMAX, "a step's pairs must fit behind what is already listed");
 #ifndef SCREEN_WAVES
 #define SCREEN_WAVES 5 // waves per SIMD the kernel is compiled for
 #endif
@@ -82,7 +82,8 @@ __device__ __forceinline__ uint32_t graze_quick(const GrazeCtx &g, const DPrim *
 #define SCREEN_REC_CLOSED 1u   // start points in closed form
 #define SCREEN_REC_SORTED 2u   // the record sorts its samples: its list carries cell masks
 #define SCREEN_REC_NO_BLOCK 4u // the pool is too small for this frame: no list
-#define SCREEN_REC_OPEN 8u     // shaded without screens (set by phases 2 and 3)
+#define SCREEN_REC_OPEN 8u     // shaded without screens (set by phase 3)
+#define SCREEN_REC_PAIRS 16u   // (measurement build) the record listed pairs
 struct alignas(16) ScreenRec {
     RayFan fan;
     float oz_first, oz_last; // (the fan keeps the start points' z times sigma)
@@ -98,7 +99,8 @@ struct ScreenLds {
     ScreenRec rec[SCREEN_BATCH];
     uint32_t pair[SCREEN_GRAZE_LIST]; // primitive offset in the leaf | sample << 16
     uint8_t slot[SCREEN_GRAZE_LIST];  // the pair's record: index in rec[]
-    uint32_t n_pairs;                 // listed so far (may exceed the list: the excess is not stored)
+    uint32_t end[SCREEN_BATCH];       // primitives of records 0 .. r of the batch
+    uint32_t n_pairs;                 // listed and not yet checked
     uint32_t pad[3];
 };
 
@@ -151,6 +153,7 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
     for (uint32_t batch = wave_id; batch < n_batches; batch += n_waves) {
         const uint32_t nb = min(SCREEN_BATCH, (map.total - batch + n_batches - 1u) / n_batches);
         // ---- phase 1: a record per lane ----
+        uint32_t my_prims = 0; // this lane's record: primitives it sends through phase 2
         if (lane < nb) {
             ScreenRec c;
             c.ridx = rec_index(map, lane * n_batches + batch);
@@ -173,103 +176,114 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
             c.flags = (closed ? SCREEN_REC_CLOSED : 0u) | (record_sorts(fr, c.count, closed) ? SCREEN_REC_SORTED : 0u) |
                       (((unsigned long long)c.off + c.count > pool_cap) ? SCREEN_REC_NO_BLOCK : 0u);
             L.rec[lane] = c;
+            my_prims = (c.flags & SCREEN_REC_NO_BLOCK) ? 0u : c.count;
+        }
+        // the leaves of the batch one after the other: end[r] = primitives of records 0 .. r
+        // (a record without a block in the pool takes no part)
+        {
+            uint32_t incl = my_prims;
+#pragma unroll
+            for (int off = 1; off < (int)SCREEN_BATCH; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= (uint32_t)off) incl += up;
+            }
+            if (lane < SCREEN_BATCH) L.end[lane] = incl;
         }
         if (lane == 0) L.n_pairs = 0u;
         wave_lds_sync();
-        // ---- phase 2: record after record, a primitive per lane ----
-        uint32_t my_n_cand = 0; // lane r: entries of record r's list
-        uint32_t n_listed = 0;  // pairs of the records so far
-        for (uint32_t r = 0; r < nb; r++) {
-            const ScreenRec c = L.rec[r];
-            if (c.flags & SCREEN_REC_NO_BLOCK) continue;
-            const bool closed = (c.flags & SCREEN_REC_CLOSED) != 0u, sorted = (c.flags & SCREEN_REC_SORTED) != 0u;
-            const DPrim *__restrict__ leaf_prims = prims + c.first;
-            uint32_t *__restrict__ out = pool + c.off;
-#ifdef NO_GRAZE
-            const bool screened = false; // (measurement build only: the screens without their guard)
-#else
-            const bool screened = c.fan.margin < 1.0e38f;
+        // ---- phase 2: the batch's primitives as one stream, a primitive per lane ----
+        // Lane l of a step takes primitive f0 + l of the stream, whatever record it belongs to (a
+        // leaf has 20 to 70 primitives on average: record by record a step would fill a third to
+        // a half of the lanes).  How far outside the rays' pyramid the primitive lies
+        // (fan_separation; records with samples in index order use the same planes), for a record
+        // that sorts its samples the light cells it can be hit from, the grazing guard for what is
+        // dropped or left out of cells, and the survivors appended to their record's block.
+        const uint32_t total_prims = L.end[nb - 1u];
+        uint32_t my_n_cand = 0; // lane r: entries of record r's list so far
+        uint32_t n_listed = 0;  // pairs listed and not yet checked
+        uint32_t r_lo = 0;      // first record with primitives at or beyond f0
+        for (uint32_t f0 = 0; f0 < total_prims; f0 += 64) {
+            if (n_listed > SCREEN_GRAZE_LIST - 64u * GRAZE_KMAX) { // room for whatever this step lists
+#ifdef STEP_STATS
+                st_pairs += n_listed;
 #endif
-            const GrazeCtx G = graze_ctx(closed, f3_make(c.fan.ox[0], c.fan.oy[0], c.oz_first),
-                                         f3_make(c.fan.ox[1], c.fan.oy[1], c.oz_last), fr.n_lights, fr.cull_margin, c.fan.margin);
-            if (n_listed > SCREEN_GRAZE_FLUSH) { // room for this record's pairs
                 screen_resolve(fr, prims, L, n_listed, lane);
                 if (lane == 0) L.n_pairs = 0u;
                 n_listed = 0;
                 wave_lds_sync();
             }
-            uint32_t n_cand;
-            for (;;) {
-                // One pass over the leaf: how far outside the rays' pyramid a primitive lies
-                // (fan_separation; records with samples in index order use the same planes), for a
-                // record that sorts its samples the light cells it can be hit from, the grazing guard
-                // for what is dropped or left out of cells, and the survivors appended to the block.
-                n_cand = 0;
-                for (uint32_t base = 0; base < c.count; base += 64) {
-                    const uint32_t t = base + lane;
-                    bool keep = false;
-                    uint32_t cells = 0xFFFFu, code = 0, first = 0, cnt = 0;
-                    if (t < c.count) {
-                        const DPrim *__restrict__ p = leaf_prims + t;
-                        keep = true;
-                        if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
-                            float sep;
-                            if (sorted) {
-                                fan_screen(c.fan, p->a, p->b, p->c, sep, cells);
-                            } else {
-                                sep = fan_separation(c.fan, p->a, p->b, p->c);
-                            }
-                            keep = !(sep > c.fan.margin);
-                            if (!keep) cells = 0xFFFFu; // (dropped altogether: the guard looks at it once)
-                            if (screened && (!keep || cells != 0xFFFFu)) {
-                                // (left out of a cell: by the margin at least)
-                                code = graze_quick(G, p, keep ? c.fan.margin : sep, first, cnt);
-                                if (code == 2u) {
-                                    keep = true;
-                                    cells = 0xFFFFu;
-                                }
-                            }
+            while (L.end[r_lo] <= f0) r_lo++;
+            r_lo = __builtin_amdgcn_readfirstlane(r_lo); // (the same in every lane)
+            const uint32_t f = f0 + lane;
+            const bool valid = f < total_prims;
+            uint32_t r = r_lo;
+            if (valid)
+                while (L.end[r] <= f) r++;
+            const uint32_t r_hi = __builtin_amdgcn_readlane(r, (int)(min(total_prims - f0, 64u) - 1u));
+            bool keep = false;
+            uint32_t cells = 0xFFFFu, code = 0, first = 0, cnt = 0, t = 0;
+            uint32_t *__restrict__ out = pool;
+            if (valid) {
+                const ScreenRec &c = L.rec[r];
+                t = f - (r ? L.end[r - 1u] : 0u);
+                out = pool + c.off;
+                const DPrim *__restrict__ p = prims + c.first + t;
+                keep = true;
+                if ((p->type_mat & 0xFFu) == RTX_PRIM_TRIANGLE) {
+                    const RayFan fan = c.fan;
+                    const bool closed = (c.flags & SCREEN_REC_CLOSED) != 0u, sorted = (c.flags & SCREEN_REC_SORTED) != 0u;
+                    float sep;
+                    if (fr.sort_samples) { // (records that will not sort their samples ignore the cells)
+                        fan_screen(fan, p->a, p->b, p->c, sep, cells);
+                        if (!sorted) cells = 0xFFFFu;
+                    } else {
+                        sep = fan_separation(fan, p->a, p->b, p->c);
+                    }
+                    keep = !(sep > fan.margin);
+                    if (!keep) cells = 0xFFFFu; // (dropped altogether: the guard looks at it once)
+#ifdef NO_GRAZE
+                    const bool screened = false; // (measurement build only: the screens without their guard)
+#else
+                    const bool screened = fan.margin < 1.0e38f;
+#endif
+                    if (screened && (!keep || cells != 0xFFFFu)) {
+                        // (left out of a cell: by the margin at least)
+                        const GrazeCtx G = graze_ctx(closed, f3_make(fan.ox[0], fan.oy[0], c.oz_first),
+                                                     f3_make(fan.ox[1], fan.oy[1], c.oz_last), fr.n_lights, fr.cull_margin,
+                                                     fan.margin);
+                        code = graze_quick(G, p, keep ? fan.margin : sep, first, cnt);
+                        if (code == 2u) {
+                            keep = true;
+                            cells = 0xFFFFu;
                         }
                     }
-                    if (code == 1u) { // the pairs of this lane's triangle, in any order (few lanes have any)
-                        const uint32_t pos = atomicAdd(&L.n_pairs, cnt);
-                        for (uint32_t q = 0; q < cnt; q++)
-                            if (pos + q < SCREEN_GRAZE_LIST) {
-                                L.pair[pos + q] = t | ((first + q) << 16);
-                                L.slot[pos + q] = (uint8_t)r;
-                            }
-                    }
-                    const unsigned long long mask = __ballot(keep);
-                    if (keep)
-                        out[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
-                            t | (cells << 16);
-                    n_cand += (uint32_t)__popcll(mask);
                 }
-                wave_lds_sync();
-                const uint32_t total = L.n_pairs;
-                if (total <= SCREEN_GRAZE_LIST) {
-#ifdef STEP_STATS
-                    st_pairs += total - n_listed, st_recs += total != n_listed;
-#endif
-                    n_listed = total;
-                    break;
-                }
-                // The list is full.  Pairs of earlier records: check them and run this record again
-                // on the empty list; a record that overflows the list by itself goes without screens.
-                if (n_listed) screen_resolve(fr, prims, L, n_listed, lane);
-                if (lane == 0) {
-                    L.n_pairs = 0u;
-                    if (!n_listed) L.rec[r].flags = c.flags | SCREEN_REC_OPEN;
-                }
-                wave_lds_sync();
-                if (!n_listed) break;
-                n_listed = 0;
             }
-            if (lane == r) my_n_cand = n_cand;
+            if (code == 1u) { // the pairs of this lane's triangle, in any order (few lanes have any)
+                const uint32_t pos = atomicAdd(&L.n_pairs, cnt);
+                for (uint32_t q = 0; q < cnt; q++) {
+                    L.pair[pos + q] = t | ((first + q) << 16);
+                    L.slot[pos + q] = (uint8_t)r;
+                }
 #ifdef STEP_STATS
-            st_prims += c.count;
+                atomicOr(&L.rec[r].flags, SCREEN_REC_PAIRS);
 #endif
+            }
+            // the survivors, record by record of those the step touches, in stream order
+            for (uint32_t rr = r_lo; rr <= r_hi; rr++) {
+                const unsigned long long mask = __ballot(keep && r == rr);
+                const uint32_t n_rr = __builtin_amdgcn_readlane(my_n_cand, (int)rr);
+                if (keep && r == rr)
+                    out[n_rr + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
+                        t | (cells << 16);
+                if (lane == rr) my_n_cand += (uint32_t)__popcll(mask);
+            }
+            wave_lds_sync();
+            n_listed = L.n_pairs;
         }
+#ifdef STEP_STATS
+        st_prims += total_prims, st_pairs += n_listed;
+#endif
         // ---- phase 3: the listed pairs, then every record's list length ----
         if (n_listed) screen_resolve(fr, prims, L, n_listed, lane);
         uint32_t my_flags = 0, my_count = 0, my_ridx = 0;
@@ -278,6 +292,7 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
         unsigned long long open = __ballot((my_flags & SCREEN_REC_OPEN) != 0u);
 #ifdef STEP_STATS
         st_open += (unsigned long long)__popcll(open);
+        st_recs += (unsigned long long)__popcll(__ballot((my_flags & SCREEN_REC_PAIRS) != 0u));
 #endif
         while (open) {
             const uint32_t r = (uint32_t)__builtin_ctzll(open);

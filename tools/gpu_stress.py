@@ -64,6 +64,8 @@ for case in range(n_cases):
     if depth < 6 and name in ("buddha", "multi", "bunny", "dino_spheres"):
         depth = 6  # (whole meshes in a few leaves take the CPU minutes per frame)
     corner = int(rng.choice([0, 0, 0, 0, 1, 2, 3])) if os.environ.get("RTX_STRESS_CORNERS", "1") == "1" else 0
+    if corner == 2:
+        depth = max(depth, 6)  # (the added mesh in one leaf: 70 k primitives per shadow ray on the CPU)
     if corner == 1:      # very many samples on a small frame
         nl = int(rng.choice([4096, 6000, 20000]))
         acne = float(rng.choice([0.01, 0.001, 0.002]))
