@@ -18,6 +18,11 @@ out 3e-4 apart): 5e-3.  The same cancellation amplifies the fast BSDF's own 4e-5
 where the order is fixed (light at z = 30, two mirror bounces, 17 samples: a channel of -0.635
 beside one of -9.8 came out 6.9e-4 apart, and 1.9e-7 with RTX_FLAG_IEEE_SHADE -
 tools/gpu_case.py runs one case with both builds): 5e-3 there too unless the case runs the IEEE build.
+Where the order is not fixed and a record's samples have both signs (same conditions), a channel
+can cancel almost completely: seed 37's case 688 (spheres, acne -0.01, 1030 samples, two bounces) has a
+record of (0.0015, 129.4, 131.3) against the oracle's (-0.0015, 129.4, 131.3), the same with either
+build of the BSDF - 2e-5 of the record's size; such cases weigh the record's largest channel with 2e-2
+instead of 1e-3.  A NaN channel (shade.h divides 0 by 0 for some directions) must be NaN on both sides.
 
 One case in five draws from the corners the exactness arguments are weakest in: thousands
 of samples (the running acne offset leaves the straight line by many ulps), a mesh scaled
@@ -125,13 +130,22 @@ for case in range(n_cases):
     diff = np.abs(rgb_g.astype(np.int32) - rgb_c.astype(np.int32)).max(axis=2)
     within = float((diff <= 1).mean())
     rel = 0.0
+    ok_nan = True
     if ok_ids and len(hits_c):
+        # shade.h divides 0 by 0 for some degenerate directions: a NaN channel must be one on both sides
+        nan_g, nan_c = np.isnan(hits_g["color"]), np.isnan(hits_c["color"])
+        ok_nan = bool(np.array_equal(nan_g, nan_c))
+        col_g, col_c = np.where(nan_g, 0.0, hits_g["color"]), np.where(nan_c, 0.0, hits_c["color"])
         # a channel that is the small remainder of cancelling contributions carries the summation
-        # noise of the record's large channels: measure it against those as well
-        rec_max = np.abs(hits_c["color"]).max(axis=1, keepdims=True)
-        rel = float((np.abs(hits_g["color"] - hits_c["color"]) / (np.abs(hits_c["color"]) + 1e-2 + 1e-3 * rec_max)).max())
+        # noise of the record's large channels: measure it against those as well (with a light low
+        # inside the scene or a negative acne offset a record's samples have both signs and a
+        # channel can cancel to 1e-3 beside channels of 130: 2e-2 of the largest then)
+        rec_max = np.abs(col_c).max(axis=1, keepdims=True)
+        both_signs = light_z <= 150.0 or acne < 0.0
+        weight = 2e-2 if both_signs and not in_order else 1e-3
+        rel = float((np.abs(col_g - col_c) / (np.abs(col_c) + 1e-2 + weight * rec_max)).max())
     cancels = (light_z <= 150.0 or acne < 0.0) and not (flags & capi.RTX_FLAG_IEEE_SHADE)
-    ok = ok_ids and ok_t and ok_lit and ok_screen and within >= 0.999 and rel < (5e-4 if in_order and not cancels else 5e-3)
+    ok = ok_ids and ok_t and ok_lit and ok_screen and ok_nan and within >= 0.999 and rel < (5e-4 if in_order and not cancels else 5e-3)
     bad += not ok
     print("%s case %2d corner %d %-12s depth %2d light_z %6.0f acne %6.3f N %4d %dx%d flags %d bounces %d: hits %d ids %s t %s lit %s screens %s "
           "(%d vs %d) part %d/%d cam %s rgb<=1 %.5f equal %.5f rel %.2e run %.1f%%  cpu %.1fs" %
