@@ -797,7 +797,7 @@ static rtx_status render_frame(rtx_scene *s, const rtx_params *p, uint8_t *d_rgb
 #endif
         if (!few)
             screen_kernel<<<screen_blocks, SCREEN_BLOCK, 0, st>>>(fr, s->d_prims, wb.recs, wb.rec_cap, wb.cand_off, wb.cand_n,
-                                                                  wb.pool, wb.pool_cap, wb.ctr);
+                                                                  wb.pool, wb.pool_cap, wb.colors, wb.ctr);
         if (timing) HIP_TRY(hipEventRecord(s->ev[1], st)); // so that [1] is the shading kernel alone
         if (few) {
             // few samples: several hit records per wave

@@ -535,6 +535,12 @@ __device__ __forceinline__ void primary_ray_uniform(const DFrame &fr, uint32_t i
     d.z = __int_as_float(__builtin_amdgcn_readlane(bits, 2));
 }
 
+// The same value in every lane, moved to a scalar register (a float that lives as long as a record
+// is shaded is cheaper there than in a vector register).
+__device__ __forceinline__ float wave_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 // Global row of local row r of this part (rows are dealt to parts in stripes).
 __device__ __forceinline__ uint32_t part_row(const DFrame &fr, uint32_t r) {
     if (fr.n_parts <= 1) return r;

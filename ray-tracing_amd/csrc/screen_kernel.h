@@ -135,6 +135,7 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                                                               const uint32_t *__restrict__ cand_off,
                                                               uint32_t *__restrict__ cand_n,
                                                               uint32_t *__restrict__ pool, uint32_t pool_cap,
+                                                              float4 *__restrict__ colors,
                                                               DCounters *__restrict__ ctr) {
     __shared__ ScreenLds lds[SCREEN_BLOCK / 64];
     const RecMap map = rec_map(ctr, rec_cap); // final: written by the trace kernel
@@ -177,6 +178,12 @@ void screen_kernel(DFrame fr, const DPrim *__restrict__ prims,
                       (((unsigned long long)c.off + c.count > pool_cap) ? SCREEN_REC_NO_BLOCK : 0u);
             L.rec[lane] = c;
             my_prims = (c.flags & SCREEN_REC_NO_BLOCK) ? 0u : c.count;
+            // the direction the hit is seen from (raytracing.h:47: minus the primary ray's), left where
+            // the shading kernel will put the record's colour: there it is the same in all 64 lanes,
+            // an integer division and a normalisation per record
+            f3 ro, rd;
+            primary_ray(fr, rc.pixel % fr.width, rc.pixel / fr.width, ro, rd);
+            colors[c.ridx] = make_float4(-rd.x, -rd.y, -rd.z, 0.f);
         }
         // the leaves of the batch one after the other: end[r] = primitives of records 0 .. r
         // (a record without a block in the pool takes no part)

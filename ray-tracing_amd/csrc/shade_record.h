@@ -578,7 +578,12 @@ __device__ __forceinline__ void shade_record(const DFrame &fr, const DPrim *__re
         f3 nrm = f3_make(rc.nx, rc.ny, rc.nz);
         f3 p0 = f3_make(rc.px, rc.py, rc.pz);
         f3 o, d;
-        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
+        if constexpr (BOUNCE) {
+            primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
+        } else { // screen_kernel has left the view direction (-d) in the place of the record's colour
+            const float4 vw = colors[ridx];
+            d = f3_make(-wave_uniform(vw.x), -wave_uniform(vw.y), -wave_uniform(vw.z));
+        }
         uint32_t depth = 0;
         for (;;) {
         const f3 view = f3_scale(d, -1.f);      // raytracing.h:47

@@ -621,12 +621,14 @@ __device__ __forceinline__ void shade_record_sorted(const DFrame &fr, const DPri
         const DRec rc = recs[ridx];
         const uint32_t pixel = rc.pixel;
         const DMat mat = mats[rc.mat];
-        f3 o, d;
-        primary_ray_uniform(fr, pixel % fr.width, pixel / fr.width, lane, o, d);
+        // (raytracing.h:47: the hit is seen from minus the primary ray's direction; screen_kernel has
+        // left that in the place of the record's colour)
+        const float4 vw = colors[ridx];
         uint32_t lit = 0;
         const float4 sum = shade_level_sorted<IEEE, true>(fr, prims + rc.first, rc.count, pixel, rc.leaf, mat,
                                                     f3_make(rc.nx, rc.ny, rc.nz), f3_make(rc.px, rc.py, rc.pz),
-                                                    f3_scale(d, -1.f) /* raytracing.h:47 */, 0u, L, lane, tot, lit,
+                                                    f3_make(wave_uniform(vw.x), wave_uniform(vw.y), wave_uniform(vw.z)), 0u, L, lane,
+                                                    tot, lit,
                                                     lists.pool + lists.cand_off[ridx], lists.cand_n[ridx]);
         if (lane == 0) colors[ridx] = sum;
         tot.lit += lit;
